@@ -1,0 +1,206 @@
+"""Deterministic synthetic weights and inputs.
+
+The reference ships no checkpoints, so parity and the
+benchmark run on seeded synthetic ``state_dict``s that carry exactly the keys and
+shapes of ``models/gestsync.py`` / ``models/jegal.py`` (strict-loadable into the
+reference modules; ``oracle/make_golden.py`` checks that).  Everything is generated
+from ``numpy.random.default_rng(seed)`` so the GPU box reproduces it bit-for-bit.
+
+Inputs follow SURVEY.md section 8d (configs 2-5).
+"""
+import math
+
+import numpy as np
+
+GESTSYNC_SEED = 4101
+JEGAL_SEED = 4102
+
+
+def sinusoid_pe(max_len, d_model):
+    """Sin/cos table of gestsync.py:178-183 and modules.py:140-147 (fp32 math as torch does it)."""
+    import torch
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0).numpy()
+
+
+class _Gen:
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.sd = {}
+
+    def linear(self, name, out_f, in_f, relu_after=False, wname="weight", bname="bias"):
+        std = math.sqrt((2.0 if relu_after else 1.0) / in_f)
+        self.sd[f"{name}.{wname}"] = (self.rng.standard_normal((out_f, in_f)) * std).astype(np.float32)
+        self.sd[f"{name}.{bname}"] = (self.rng.standard_normal(out_f) * 0.05).astype(np.float32)
+
+    def conv(self, name, out_c, in_c, ks):
+        fan_in = in_c * int(np.prod(ks))
+        std = math.sqrt(2.0 / fan_in)
+        self.sd[f"{name}.weight"] = (self.rng.standard_normal((out_c, in_c) + tuple(ks)) * std).astype(np.float32)
+        self.sd[f"{name}.bias"] = (self.rng.standard_normal(out_c) * 0.05).astype(np.float32)
+
+    def bn(self, name, c):
+        self.sd[f"{name}.weight"] = self.rng.uniform(0.6, 1.4, c).astype(np.float32)
+        self.sd[f"{name}.bias"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+        self.sd[f"{name}.running_mean"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+        self.sd[f"{name}.running_var"] = self.rng.uniform(0.5, 1.5, c).astype(np.float32)
+        self.sd[f"{name}.num_batches_tracked"] = np.array(1000, dtype=np.int64)
+
+    def ln(self, name, c, wname="weight", bname="bias"):
+        self.sd[f"{name}.{wname}"] = self.rng.uniform(0.7, 1.3, c).astype(np.float32)
+        self.sd[f"{name}.{bname}"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+
+
+def gestsync_state_dict(seed=GESTSYNC_SEED, include_unused=True):
+    """All keys of ``GestSync().state_dict()`` (gestsync.py:9-32).
+
+    ``include_unused`` adds the audio/LSTM tensors the checkpoint carries but
+    ``forward_vid`` never touches (checkpoint row).
+    """
+    g = _Gen(seed)
+    vid = [("conv1", 64, 3, (5, 7, 7)), ("conv2", 128, 64, (1, 5, 5)), ("conv3", 256, 128, (1, 3, 3)),
+           ("conv4", 256, 256, (1, 3, 3)), ("conv5", 256, 256, (1, 3, 3)), ("fc6", 512, 256, (1, 4, 4))]
+    for i, (nm, oc, ic, ks) in enumerate(vid, 1):
+        g.conv(f"net_vid.{nm}", oc, ic, ks)
+        g.bn(f"net_vid.bn{i}", oc)
+    g.linear("ff_vid.0", 512, 512, relu_after=True)
+    g.linear("ff_vid.2", 1024, 512)
+    g.sd["pos_encoder.pe"] = sinusoid_pe(50, 512)
+    for l in range(6):
+        p = f"transformer_encoder.layers.{l}"
+        g.linear(f"{p}.self_attn", 1536, 512, wname="in_proj_weight", bname="in_proj_bias")
+        g.linear(f"{p}.self_attn.out_proj", 512, 512)
+        g.linear(f"{p}.linear1", 2048, 512, relu_after=True)
+        g.linear(f"{p}.linear2", 512, 2048)
+        g.ln(f"{p}.norm1", 512)
+        g.ln(f"{p}.norm2", 512)
+    if include_unused:
+        aud = [("conv1", 64, 1, (3, 3)), ("conv2", 192, 64, (3, 3)), ("conv3", 384, 192, (3, 3)),
+               ("conv4", 256, 384, (3, 3)), ("conv5", 256, 256, (3, 3)), ("fc6", 512, 256, (4, 2))]
+        for i, (nm, oc, ic, ks) in enumerate(aud, 1):
+            g.conv(f"net_aud.{nm}", oc, ic, ks)
+            g.bn(f"net_aud.bn{i}", oc)
+        for sfx in ("", "_reverse"):
+            g.sd[f"lstm.weight_ih_l0{sfx}"] = (g.rng.standard_normal((1024, 512)) * 0.04).astype(np.float32)
+            g.sd[f"lstm.weight_hh_l0{sfx}"] = (g.rng.standard_normal((1024, 256)) * 0.04).astype(np.float32)
+            g.sd[f"lstm.bias_ih_l0{sfx}"] = np.zeros(1024, np.float32)
+            g.sd[f"lstm.bias_hh_l0{sfx}"] = np.zeros(1024, np.float32)
+        g.conv("ff_aud.fc7", 512, 512, (1, 1))
+        g.bn("ff_aud.bn7", 512)
+        g.conv("ff_aud.fc8", 1024, 512, (1, 1))
+        g.sd["logits_scale.weight"] = np.ones((1, 1), np.float32)
+        g.sd["fc.weight"] = np.ones((1, 1), np.float32)
+        g.sd["fc.bias"] = np.zeros(1, np.float32)
+    return g.sd
+
+
+def _annotated_encoder(g, prefix, n_layers, d, d_ff):
+    for l in range(n_layers):
+        p = f"{prefix}.layers.{l}"
+        for i in range(4):
+            g.linear(f"{p}.self_attn.linears.{i}", d, d)
+        g.linear(f"{p}.feed_forward.w_1", d_ff, d, relu_after=True)
+        g.linear(f"{p}.feed_forward.w_2", d, d_ff)
+        g.ln(f"{p}.sublayer.0.norm", d, "a_2", "b_2")
+        g.ln(f"{p}.sublayer.1.norm", d, "a_2", "b_2")
+    g.ln(f"{prefix}.norm", d, "a_2", "b_2")
+
+
+def jegal_state_dict(seed=JEGAL_SEED):
+    """All keys of ``JEGAL().state_dict()`` (jegal.py:18-76)."""
+    g = _Gen(seed)
+    g.linear("proj_ip_rgb.0", 512, 1024)
+    g.ln("proj_ip_rgb.1", 512)
+    g.linear("proj_ip_rgb.3", 512, 512)
+    g.sd["position_rgb.pe"] = sinusoid_pe(500, 512)
+    _annotated_encoder(g, "encoder_rgb", 6, 512, 2048)
+    g.linear("proj_op_rgb", 512, 512)
+    _annotated_encoder(g, "encoder_text", 3, 768, 3072)
+    g.linear("proj_op_text", 256, 768)
+    cnn = [(0, 32, 1, (5, 5)), (3, 64, 32, (3, 3)), (6, 128, 64, (3, 3)), (9, 256, 128, (3, 3)),
+           (12, 256, 256, (3, 3)), (15, 256, 256, (1, 1))]
+    for idx, oc, ic, ks in cnn:
+        g.conv(f"cnn.{idx}", oc, ic, ks)
+        if idx != 15:
+            g.bn(f"cnn.{idx + 1}", oc)
+    g.linear("proj_op_audio", 256, 256)
+    for nm in ("proj_op_fusion_content", "proj_op_align_gesture", "proj_op_align_content"):
+        g.linear(f"{nm}.0", 512, 512, relu_after=True)
+        g.linear(f"{nm}.2", 512, 512)
+    return g.sd
+
+
+# --------------------------------------------------------------------------- inputs
+
+def synth_frames(seed, n_clips, n_frames, height=270, width=480, mask_rows=110):
+    """uint8 (B,T,H,W,3) clips, rows [0,mask_rows) zeroed like the face-mask rectangle
+    of inference_embs.py:264.  A low-frequency pattern is mixed
+    with noise so temporal neighbours differ but are correlated, as in video."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n_clips, n_frames, height, width, 3), np.uint8)
+    for b in range(n_clips):
+        out[b] = rng.integers(0, 256, (n_frames, height, width, 3), dtype=np.uint8)
+    out[:, :, :mask_rows] = 0
+    return out
+
+
+def synth_mel(seed, n_clips, n_mel_frames):
+    """log-mel like (B,4T,80) fp32 ~ N(8,2.5)."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((n_clips, n_mel_frames, 80)) * 2.5 + 8.0).astype(np.float32)
+
+
+def synth_text(seed, n_clips, n_words, d=768):
+    """Stand-in for XLM-R output (third-party, absent: SURVEY 8c): hidden states
+    (B,L,768), ids [0, 1000+i.., 2], one sub-word per word, offsets (0,len)."""
+    rng = np.random.default_rng(seed)
+    L = n_words + 2
+    states = rng.standard_normal((n_clips, L, d)).astype(np.float32)
+    ids = np.zeros((n_clips, L), np.int64)
+    ids[:, 1:1 + n_words] = 1000 + np.arange(n_words)[None]
+    ids[:, -1] = 2
+    offsets = np.zeros((n_clips, L, 2), np.int64)
+    offsets[:, 1:1 + n_words, 1] = 4
+    mask = np.ones((n_clips, L), np.int64)
+    return states, mask, ids, offsets
+
+
+def synth_boundaries(n_clips, n_words, stride=15, length=10):
+    return [[[f"w{i}", stride * i, stride * i + length] for i in range(n_words)] for _ in range(n_clips)]
+
+
+def planted_retrieval(seed, n, d=512, noise=0.2):
+    """g_i ~ N(0,I) normalised, c_i = normalise(g_i + noise*N(0,I)).
+    ``noise`` 0.2 keeps Recall@K away from both 0 and 1 at N=10k."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((n, d)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    c = g + np.float32(noise) * rng.standard_normal((n, d)).astype(np.float32)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    return g.astype(np.float32), c.astype(np.float32)
+
+
+def planted_spotting(seed, n_clips, n_frames=150, n_words=30, d=512, noise=1.2):
+    """boundaries [w_j, 5j, 5j+4], target word uniform; gesture rows
+    in the target span replaced by normalise(c_target + noise*N)."""
+    rng = np.random.default_rng(seed)
+    gest, cont, bounds, targets = [], [], [], []
+    for _ in range(n_clips):
+        c = rng.standard_normal((n_words, d)).astype(np.float32)
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        g = rng.standard_normal((n_frames, d)).astype(np.float32)
+        g /= np.linalg.norm(g, axis=1, keepdims=True)
+        wb = [[f"w{j}", 5 * j, 5 * j + 4] for j in range(n_words)]
+        t = int(rng.integers(0, n_words))
+        s, e = wb[t][1], wb[t][2]
+        seg = c[t][None] + np.float32(noise / math.sqrt(d) * 4.0) * rng.standard_normal((e - s + 1, d)).astype(np.float32)
+        g[s:e + 1] = seg / np.linalg.norm(seg, axis=1, keepdims=True)
+        gest.append(g)
+        cont.append(c)
+        bounds.append(wb)
+        targets.append(t)
+    return gest, cont, bounds, targets

@@ -1,0 +1,173 @@
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+Usage:  python oracle/make_golden.py            (needs /root/reference; never runs on the GPU box)
+
+The reference's ``models.gestsync`` / ``models.jegal`` / ``evaluation.evaluate_*`` modules are
+imported from /root/reference with two stubs for the HuggingFace downloads at
+``models/jegal.py:13-14`` (no network here; XLM-R is third-party and out of the pinned
+scope) and ``Tensor.cuda`` made a no-op (the reference hard-codes .cuda()).
+The synthetic state_dicts of ``jegal_amd/synth.py`` are loaded with strict=True, which pins
+every key name and shape.  Only inputs-by-seed and the reference's OUTPUTS are stored; no
+reference source is copied.
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from jegal_amd import synth  # noqa: E402
+
+
+def _import_reference():
+    import transformers
+
+    class _Tok:
+        cls_token_id, sep_token_id, pad_token_id = 0, 2, 1
+
+    transformers.AutoTokenizer.from_pretrained = staticmethod(lambda *a, **k: _Tok())
+    transformers.XLMRobertaModel.from_pretrained = staticmethod(lambda *a, **k: None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    from models.gestsync import GestSync
+    from models.jegal import JEGAL
+    return GestSync, JEGAL
+
+
+def _load(model, sd):
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return model.eval()
+
+
+def _import_eval(name):
+    """evaluation/*.py parse argv at import (evaluate_spotting.py:11-15)."""
+    argv = sys.argv
+    sys.argv = [name, "--path", "/tmp", "--file", "/tmp/x.csv"] if name == "evaluate_asd" else [name, "--path", "/tmp"]
+    sys.path.insert(0, os.path.join(REF, "evaluation"))
+    try:
+        mod = __import__(name)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def _reference_functions(path, names):
+    """Pull plain functions out of a reference script that cannot be imported
+    (inference_embs.py imports mediapipe/decord/whisperx) and exec them as-is."""
+    src = open(path, encoding="utf-8").read()
+    tree = ast.parse(src)
+    ns = {"string": __import__("string")}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    return ns
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    GestSync, JEGAL = _import_reference()
+    gs = _load(GestSync(), synth.gestsync_state_dict())
+    jg = _load(JEGAL(), synth.jegal_state_dict())
+
+    with torch.no_grad():
+        # (i) GestSync clip: the reference's literal window loop (inference_embs.py:476-522)
+        T = 6
+        frames = synth.synth_frames(9001, 1, T)[0]                        # (T,270,480,3) u8
+        f01 = np.pad(frames / 255., ((12, 12), (0, 0), (0, 0), (0, 0)), "edge")
+        f01 = torch.FloatTensor(f01).unsqueeze(0)                         # (1,P,H,W,3)
+        wins = [f01[:, i:i + 25] for i in range(f01.shape[1] - 24)]
+        x = torch.stack(wins)[:, 0].permute(0, 4, 1, 2, 3)                # (N,3,25,270,480)
+        out, out_conv = gs.forward_vid(x, return_feats=True)
+        feats = out.mean(-1)
+        c1 = gs.net_vid.mp1(torch.relu(gs.net_vid.bn1(gs.net_vid.conv1(x[:1]))))   # (1,64,21,43,78)
+        np.savez_compressed(os.path.join(OUT, "gestsync_clip.npz"), seed=9001, T=T,
+                            feats=feats.numpy(), out_conv=out_conv.numpy(), out_full=out[:2].numpy(),
+                            conv1_pool_t0=c1[0, :, 0, ::6, ::6].numpy())
+
+        # (ii) JEGAL gesture branch, one padded clip
+        rng = np.random.default_rng(9002)
+        vf = rng.standard_normal((2, 40, 1024)).astype(np.float32)
+        vf[1, 30:] = 0
+        vm = np.ones((2, 40), np.float32)
+        vm[1, 30:] = 0
+        g = jg.forward_inference(visual_feats=torch.from_numpy(vf), visual_mask=torch.from_numpy(vm))
+        fg = jg.forward_gestures(torch.from_numpy(vf), torch.from_numpy(vm).unsqueeze(1))
+        np.savez_compressed(os.path.join(OUT, "jegal_gesture.npz"), seed=9002, gesture=g.numpy(), fwd_gestures=fg.numpy())
+
+        # (iii) audio branch -> content
+        mel = synth.synth_mel(9003, 2, 160)
+        wb = [[["a", 3, 9], ["b", 10, 10], ["c", 12, 30]], [["d", 0, 5], ["e", 6, 20]]]
+        am = torch.ones(2, 40)
+        c_a = jg.forward_inference(audio=torch.from_numpy(mel), audio_mask=am, word_boundaries=wb)
+        fa = jg.forward_audio(torch.from_numpy(mel))
+        np.savez_compressed(os.path.join(OUT, "jegal_audio.npz"), seed=9003, content=c_a.numpy(), fwd_audio=fa.numpy())
+
+        # (iv) text branch: synthetic XLM-R states incl. a multi-sub-word word and a padded row
+        rng = np.random.default_rng(9004)
+        L = 9
+        states = rng.standard_normal((2, L, 768)).astype(np.float32)
+        ids = np.array([[0, 11, 12, 13, 14, 15, 16, 2, 1], [0, 21, 22, 23, 2, 1, 1, 1, 1]], np.int64)
+        # clip 0: words start at tokens 1,2(+3 continuation),4,5(+6 continuation) ; clip 1: 3 words
+        offs = np.zeros((2, L, 2), np.int64)
+        offs[0, :, 0] = [0, 0, 0, 3, 0, 0, 2, 0, 0]
+        offs[0, :, 1] = [0, 4, 3, 6, 5, 2, 7, 0, 0]
+        offs[1, :, 0] = [0, 0, 0, 0, 0, 0, 0, 0, 0]
+        offs[1, :, 1] = [0, 3, 3, 3, 0, 0, 0, 0, 0]
+        tmask = (ids != 1).astype(np.int64)
+        tbatch = [["w0", "w1", "w2", "w3"], ["x0", "x1", "x2"]]
+        pack = (torch.from_numpy(states), torch.from_numpy(tmask), tbatch, torch.from_numpy(ids), torch.from_numpy(offs))
+        jg.get_roberta_embeddings = lambda text: pack
+        c_t = jg.forward_inference(text=["w0 w1 w2 w3", "x0 x1 x2"])
+        ft = jg.forward_text(torch.from_numpy(states), torch.from_numpy(tmask).unsqueeze(1))
+        np.savez_compressed(os.path.join(OUT, "jegal_text.npz"), seed=9004, states=states, ids=ids, offsets=offs,
+                            mask=tmask, content=c_t.numpy(), fwd_text=ft.numpy())
+
+        # (v) vta: all three modalities (W must agree between text and audio per clip: 4 and 3 -> audio boundaries)
+        wb2 = [[["w0", 2, 6], ["w1", 7, 12], ["w2", 13, 13], ["w3", 15, 30]], [["x0", 1, 4], ["x1", 5, 9], ["x2", 10, 22]]]
+        g2, c2 = jg.forward_inference(visual_feats=torch.from_numpy(vf), visual_mask=torch.from_numpy(vm),
+                                      text=["w0 w1 w2 w3", "x0 x1 x2"], audio=torch.from_numpy(mel),
+                                      audio_mask=am, word_boundaries=wb2)
+        np.savez_compressed(os.path.join(OUT, "jegal_vta.npz"), gesture=g2.numpy(), content=c2.numpy())
+
+    # (vi) metric goldens from evaluation/*.py
+    er = _import_eval("evaluate_retrieval")
+    es = _import_eval("evaluate_spotting")
+    ea = _import_eval("evaluate_asd")
+    g_emb, c_emb = synth.planted_retrieval(9005, 64)
+    g_emb[7] = g_emb[3]                       # duplicate gallery row -> exact tie with the diagonal in rows 3 and 7
+    sim = er.get_similarity_matrix(list(c_emb), list(g_emb))
+    m = er.compute_metrics(sim.numpy())
+    gest, cont, bounds, targets = synth.planted_spotting(9006, 20, n_frames=60, n_words=10, noise=2.0)
+    rows = [types.SimpleNamespace(target_word_boundary=str(b[t])) for b, t in zip(bounds, targets)]
+    acc = es.get_spotting_acc(rows, gest, cont, [str(b) for b in bounds])
+    attn0, _ = es.get_attn_matrix(0, gest, cont, [str(b) for b in bounds])
+    asd = {}
+    q = torch.from_numpy(c_emb[:1])
+    for P in (2, 4, 6):
+        asd[f"asd{P}"] = ea.get_similarity_cos(q, torch.from_numpy(g_emb[:P]))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), sim=sim.numpy(), R5=m["R5"], R10=m["R10"], R25=m["R25"],
+                        R50=m["R50"], MR=m["MR"], spot_acc=acc, attn0=attn0, **asd)
+
+    # (vii) text-file grammar: the reference's own load_text on its own sample
+    ns = _reference_functions(os.path.join(REF, "inference_embs.py"), {"validate_text_file", "preprocess_text", "load_text"})
+    import json
+    res = {}
+    for s in ("sample1", "sample2"):
+        text, wbs = ns["load_text"](os.path.join(REF, "samples", s + ".txt"))
+        res[s] = {"text": text, "word_boundaries": wbs, "file": open(os.path.join(REF, "samples", s + ".txt"), encoding="utf-8").read()}
+    with open(os.path.join(OUT, "load_text.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
