@@ -1,0 +1,113 @@
+/* libjegal_hip -- C ABI of the MI355X-native JEGAL embedding-extraction engine.
+ *
+ * The reference (Sindhu-Hegde/jegal) has no FFI layer: its boundary for this path is the Python
+ * method surface of two nn.Modules plus two on-disk formats.  Each entry
+ * point below names the reference interface it replaces (file:line under the reference tree).
+ * The Python facade in jegal_amd/ binds these with ctypes and re-creates the reference signatures
+ * (GestSync.forward_vid, JEGAL.forward_inference, ...); INTEGRATION.md shows the binding.
+ *
+ * Conventions: opaque handle per GPU/process (not thread-safe), caller-owned buffers, every
+ * function returns 0 on success or a negative code with jg_last_error() describing it, no
+ * exceptions cross the boundary.  All data pointers are DEVICE pointers unless the parameter name
+ * ends in _host.  Work is enqueued on the handle's HIP stream (jg_set_stream) and is asynchronous
+ * unless stated; jg_sync waits for it.
+ */
+#ifndef JEGAL_HIP_H
+#define JEGAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jg_handle jg_handle;
+
+enum { JG_OK = 0, JG_ERR_ARG = -1, JG_ERR_HIP = -2, JG_ERR_STATE = -3, JG_ERR_WEIGHT = -4 };
+
+/* dtype codes for jg_load_tensor / frame buffers */
+enum { JG_F32 = 0, JG_F16 = 1, JG_I64 = 2, JG_U8 = 3 };
+
+/* operand precision (DESIGN.md "precision"): fp32 accumulate / residual / LN / softmax in all modes */
+enum {
+    JG_PREC_FP16 = 0,     /* every GEMM/conv operand fp16 */
+    JG_PREC_FP16_W2 = 1,  /* default: Linear weights carried as hi+lo fp16 pair (2 MFMAs) */
+    JG_PREC_FP16_W2_ALL = 2 /* conv weights split as well */
+};
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int jg_create(int device, jg_handle** out);
+int jg_destroy(jg_handle* h);
+const char* jg_last_error(jg_handle* h);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own */
+int jg_set_stream(jg_handle* h, void* hip_stream);
+int jg_set_precision(jg_handle* h, int mode);
+/* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */
+int jg_set_chunk(jg_handle* h, int clips_per_chunk);
+int jg_sync(jg_handle* h);
+
+/* ---- weights: replaces model.load_state_dict(sd) (inference_embs.py:92-119,
+ *      evaluation/extract_jegal_embs.py:32-53).  `name` is the reference state_dict key with any
+ *      "module." prefix already stripped; unknown keys (net_aud.*, lstm.*, ...) are accepted and
+ *      ignored, missing hot-path keys make jg_finalize_weights fail (strict). ------------------- */
+int jg_load_tensor(jg_handle* h, const char* name, const void* data_host, const int64_t* shape_host, int ndim, int dtype);
+/* which: 1 = GestSync, 2 = JEGAL, 3 = both.  Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo. */
+int jg_finalize_weights(jg_handle* h, int which);
+
+/* ---- GestSync (models/gestsync.py) ---------------------------------------------------------- */
+/* Per-clip features: frames (B,T,270,480,3) u8 (JG_U8, the /255 of inference_embs.py:282 is applied
+ * inside) or fp32 in [0,1] (JG_F32) -> edge-pad 12 (inference_embs.py:283) -> T windows of 25
+ * (inference_embs.py:488-492) -> forward_vid -> mean(-1) (inference_embs.py:511) -> (B,T,1024) fp32.
+ * The conv stack runs once over the padded clip (window de-duplication, exact). */
+int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, int T, float* out_feats);
+/* Drop-in for GestSync.forward_vid(x, return_feats) (gestsync.py:148-162): x (N,3,25,270,480) fp32
+ * -> out (N,1024,21) fp32, optional out_conv (N,512,21) fp32 (NULL to skip). */
+int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv);
+
+/* ---- JEGAL (models/jegal.py) ---------------------------------------------------------------- */
+/* forward_gestures (jegal.py:78-92) [+ proj_op_align_gesture, jegal.py:381 when align != 0]:
+ * feats (B,T,1024) fp32, mask (B,T) fp32 (1 valid / 0 pad) or NULL -> out (B,T,512) fp32. */
+int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out);
+/* forward_audio (jegal.py:105-113): mel (B,Tm,80) fp32 -> out (B,Ta,256) fp32, Ta = jg_audio_len(Tm). */
+int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out);
+int jg_audio_len(int Tm);
+/* forward_text (jegal.py:95-103): states (B,L,768) fp32 (XLM-R last_hidden_state), mask (B,L) -> (B,L,256). */
+int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, int L, float* out);
+/* word pooling (jegal.py:174-180,189-195,233-239): for each int32 triplet (start_row,end_row_excl,dst_row)
+ * dst[dst_row][dst_col : dst_col+D] = mean(seq[start:end]).  seg is a DEVICE pointer. */
+int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n_seg, float* dst, int dst_ld, int dst_col);
+/* cat((audio,text),-1) -> proj_op_fusion_content -> proj_op_align_content (jegal.py:406-415):
+ * fused (rows,512) fp32 (audio cols 0..255, text cols 256..511, zero-padded rows) -> out (rows,512). */
+int jg_fuse_content(jg_handle* h, const float* fused, int rows, float* out);
+/* F.normalize(p=2,dim=-1) (inference_embs.py:631,635; extract_jegal_embs.py:111,115); in == out allowed */
+int jg_l2norm(jg_handle* h, const float* in, float* out, int rows, int D);
+/* frames -> unit-norm gesture embedding (B,T,512) without leaving the device (the v-only path of
+ * inference_embs.py:526-646): jg_gestsync_clip + jg_jegal_gestures(align=1) + jg_l2norm. */
+int jg_extract_gesture(jg_handle* h, const void* frames, int frames_dtype, int B, int T, float* out_emb);
+
+/* ---- metrics (evaluation/evaluate_*.py) ----------------------------------------------------- */
+/* temporal mean of ragged blocks (evaluate_retrieval.py:30-31): out[i] = mean(x[off[i]:off[i+1]]) */
+int jg_pool_mean(jg_handle* h, const float* x, const int32_t* offsets, int n, int D, float* out);
+/* evaluate_retrieval.py:38-65 on already-normalised rows: rank/ties of the diagonal per local row */
+int jg_sim_rank(jg_handle* h, const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
+                int32_t* rank, int32_t* ties);
+/* evaluate_spotting.py:39-82: per clip first-argmax frame and its softmax score for word `target` */
+int jg_spot(jg_handle* h, const float* gesture, const float* content, const int32_t* g_offsets, const int32_t* c_offsets,
+            const int32_t* target, int n_clips, int D, float temp, int32_t* pred, float* score);
+/* evaluate_asd.py:43-51,94-100: pred (n,3) = argmax over the first 2/4/6 candidates */
+int jg_asd(jg_handle* h, const float* query, const float* cand, const int32_t* c_offsets, int n, int D, float temp, int32_t* pred);
+
+/* ---- profiling: HIP-event timing per stage on the handle's stream -------------------------- */
+enum { JG_ST_STACK = 0, JG_ST_CONV1, JG_ST_POOL, JG_ST_CONV, JG_ST_GEMM, JG_ST_ATTN, JG_ST_NORM, JG_ST_MISC, JG_ST_COUNT };
+int jg_profile_enable(jg_handle* h, int on);
+/* synchronises, then returns accumulated milliseconds and launch count of a stage since the last reset */
+int jg_profile_get(jg_handle* h, int stage, double* ms, int64_t* launches);
+int jg_profile_reset(jg_handle* h);
+const char* jg_stage_name(int stage);
+/* bytes currently held by the workspace arena */
+int64_t jg_workspace_bytes(jg_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

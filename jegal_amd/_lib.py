@@ -1,0 +1,325 @@
+"""ctypes binding of libjegal_hip.so (include/jegal_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded,
+importing the engine raises.  PyTorch is used only for device memory and streams; every
+tensor op of the hot path runs inside the library.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch  # imported first so libamdhip64.so.7 resolves to the runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjegal_hip.so")
+
+JG_F32, JG_F16, JG_I64, JG_U8 = 0, 1, 2, 3
+PREC_FP16, PREC_FP16_W2, PREC_FP16_W2_ALL = 0, 1, 2
+STAGES = ["stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc"]
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_SIGS = {
+    "jg_create": [_I, ctypes.POINTER(_P)],
+    "jg_destroy": [_P],
+    "jg_set_stream": [_P, _P],
+    "jg_set_precision": [_P, _I],
+    "jg_set_chunk": [_P, _I],
+    "jg_sync": [_P],
+    "jg_load_tensor": [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I, _I],
+    "jg_finalize_weights": [_P, _I],
+    "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
+    "jg_gestsync_windows": [_P, _P, _I, _P, _P],
+    "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
+    "jg_jegal_audio": [_P, _P, _I, _I, _P],
+    "jg_audio_len": [_I],
+    "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
+    "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
+    "jg_fuse_content": [_P, _P, _I, _P],
+    "jg_l2norm": [_P, _P, _P, _I, _I],
+    "jg_extract_gesture": [_P, _P, _I, _I, _I, _P],
+    "jg_pool_mean": [_P, _P, _P, _I, _I, _P],
+    "jg_sim_rank": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "jg_spot": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _P],
+    "jg_asd": [_P, _P, _P, _P, _I, _I, ctypes.c_float, _P],
+    "jg_profile_enable": [_P, _I],
+    "jg_profile_get": [_P, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)],
+    "jg_profile_reset": [_P],
+}
+EXPORTS = sorted(list(_SIGS) + ["jg_last_error", "jg_stage_name", "jg_workspace_bytes"])
+
+_lib = None
+
+
+def load_library():
+    """Load libjegal_hip.so or raise.  No fallback by design."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C jegal_amd/csrc`).  jegal_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _I
+    lib.jg_last_error.argtypes = [_P]
+    lib.jg_last_error.restype = ctypes.c_char_p
+    lib.jg_stage_name.argtypes = [_I]
+    lib.jg_stage_name.restype = ctypes.c_char_p
+    lib.jg_workspace_bytes.argtypes = [_P]
+    lib.jg_workspace_bytes.restype = ctypes.c_int64
+    _lib = lib
+    return lib
+
+
+class JegalError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One jg_handle on one GPU.  Not thread-safe; one per process/GPU."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("jegal_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if idx not in cls._cache:
+            cls._cache[idx] = cls(idx)
+        return cls._cache[idx]
+
+    def __init__(self, device_index=0, precision=None):
+        self.lib = load_library()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.init()
+        with torch.cuda.device(self.device):
+            torch.zeros(1, device=self.device)          # make sure the HIP context exists
+        h = _P()
+        rc = self.lib.jg_create(device_index, ctypes.byref(h))
+        if rc != 0:
+            raise JegalError(f"jg_create({device_index}) failed with {rc}")
+        self.h = h
+        if precision is not None:
+            self._ck(self.lib.jg_set_precision(self.h, precision))
+        self.finalized = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.jg_destroy(self.h)
+            self.h = None
+            for k, v in list(Engine._cache.items()):
+                if v is self:
+                    del Engine._cache[k]
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise JegalError(f"libjegal_hip error {rc}: {self.lib.jg_last_error(self.h).decode()}")
+
+    def _bind_stream(self):
+        self._ck(self.lib.jg_set_stream(self.h, _P(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # ---- weights
+    def set_precision(self, mode):
+        self._ck(self.lib.jg_set_precision(self.h, mode))
+
+    def set_chunk(self, clips):
+        self._ck(self.lib.jg_set_chunk(self.h, int(clips)))
+
+    def load_tensors(self, state_dict):
+        for name, val in state_dict.items():
+            if isinstance(val, torch.Tensor):
+                val = val.detach().cpu().numpy()
+            arr = np.asarray(val)
+            if arr.dtype == np.float16:
+                code = JG_F16
+            elif arr.dtype == np.int64:
+                code = JG_I64
+            else:
+                arr = arr.astype(np.float32, copy=False)
+                code = JG_F32
+            arr = np.ascontiguousarray(arr)
+            shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            self._ck(self.lib.jg_load_tensor(self.h, name.encode(), arr.ctypes.data_as(_P), shape, arr.ndim, code))
+
+    def finalize(self, which):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.jg_finalize_weights(self.h, which))
+        self.finalized |= which
+
+    # ---- helpers
+    def _f32(self, t):
+        return torch.as_tensor(t, device=self.device).to(torch.float32).contiguous()
+
+    def _i32(self, a):
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.int32)), device=self.device)
+
+    def sync(self):
+        self._ck(self.lib.jg_sync(self.h))
+
+    # ---- GestSync
+    def gestsync_clip(self, frames):
+        """frames (B,T,270,480,3) uint8 or float32 cuda tensor -> (B,T,1024) fp32."""
+        self._bind_stream()
+        frames = frames.to(self.device)
+        if frames.dtype == torch.uint8:
+            code = JG_U8
+        else:
+            frames, code = frames.to(torch.float32), JG_F32
+        frames = frames.contiguous()
+        B, T, H, W, C = frames.shape
+        if (H, W, C) != (270, 480, 3):
+            raise ValueError(f"frames must be (B,T,270,480,3), got {tuple(frames.shape)}")
+        out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
+        return out
+
+    def gestsync_windows(self, x, return_feats=False):
+        self._bind_stream()
+        x = self._f32(x)
+        if tuple(x.shape[1:]) != (3, 25, 270, 480):
+            raise ValueError(f"x must be (N,3,25,270,480), got {tuple(x.shape)}")
+        N = x.shape[0]
+        out = torch.empty((N, 1024, 21), dtype=torch.float32, device=self.device)
+        oc = torch.empty((N, 512, 21), dtype=torch.float32, device=self.device) if return_feats else None
+        self._ck(self.lib.jg_gestsync_windows(self.h, _ptr(x), N, _ptr(out), _ptr(oc)))
+        return (out, oc) if return_feats else out
+
+    def extract_gesture(self, frames, out=None):
+        """frames -> unit-norm gesture embedding (B,T,512), one library call."""
+        self._bind_stream()
+        if frames.dtype == torch.uint8:
+            code = JG_U8
+        else:
+            frames, code = frames.to(torch.float32), JG_F32
+        frames = frames.contiguous()
+        B, T = frames.shape[:2]
+        if out is None:
+            out = torch.empty((B, T, 512), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_extract_gesture(self.h, _ptr(frames), code, B, T, _ptr(out)))
+        return out
+
+    # ---- JEGAL
+    def jegal_gestures(self, feats, mask=None, align=False):
+        self._bind_stream()
+        feats = self._f32(feats)
+        B, T, D = feats.shape
+        if D != 1024:
+            raise ValueError("visual feats must have 1024 channels")
+        m = None if mask is None else self._f32(mask).reshape(B, T)
+        out = torch.empty((B, T, 512), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_jegal_gestures(self.h, _ptr(feats), _ptr(m), B, T, int(bool(align)), _ptr(out)))
+        return out
+
+    def audio_len(self, Tm):
+        return int(self.lib.jg_audio_len(int(Tm)))
+
+    def jegal_audio(self, mel):
+        self._bind_stream()
+        mel = self._f32(mel)
+        B, Tm, F = mel.shape
+        if F != 80:
+            raise ValueError("mel must have 80 bands")
+        out = torch.empty((B, self.audio_len(Tm), 256), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_jegal_audio(self.h, _ptr(mel), B, Tm, _ptr(out)))
+        return out
+
+    def jegal_text(self, states, mask=None):
+        self._bind_stream()
+        states = self._f32(states)
+        B, L, D = states.shape
+        if D != 768:
+            raise ValueError("text states must have 768 channels")
+        m = None if mask is None else self._f32(mask).reshape(B, L)
+        out = torch.empty((B, L, 256), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_jegal_text(self.h, _ptr(states), _ptr(m), B, L, _ptr(out)))
+        return out
+
+    def word_pool(self, seq, segments, dst, dst_col):
+        """seq (rows,D) fp32; segments int (n,3) = (start,end_excl,dst_row); dst (rows_out, ld) fp32."""
+        self._bind_stream()
+        seg = self._i32(segments).reshape(-1, 3)
+        if seg.shape[0] == 0:
+            return
+        self._ck(self.lib.jg_word_pool(self.h, _ptr(seq), seq.shape[-1], _ptr(seg), seg.shape[0], _ptr(dst), dst.shape[-1], dst_col))
+
+    def fuse_content(self, fused):
+        self._bind_stream()
+        fused = self._f32(fused)
+        rows = fused.numel() // 512
+        out = torch.empty_like(fused)
+        self._ck(self.lib.jg_fuse_content(self.h, _ptr(fused), rows, _ptr(out)))
+        return out
+
+    def l2norm(self, x):
+        self._bind_stream()
+        x = self._f32(x)
+        out = torch.empty_like(x)
+        D = x.shape[-1]
+        self._ck(self.lib.jg_l2norm(self.h, _ptr(x), _ptr(out), x.numel() // D, D))
+        return out
+
+    # ---- metrics
+    def pool_mean(self, x, offsets):
+        self._bind_stream()
+        x = self._f32(x)
+        off = self._i32(offsets)
+        n = off.numel() - 1
+        out = torch.empty((n, x.shape[-1]), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_pool_mean(self.h, _ptr(x), _ptr(off), n, x.shape[-1], _ptr(out)))
+        return out
+
+    def sim_rank(self, e1, e2, row_offset=0):
+        self._bind_stream()
+        e1, e2 = self._f32(e1), self._f32(e2)
+        n_local, D = e1.shape
+        rank = torch.empty(n_local, dtype=torch.int32, device=self.device)
+        ties = torch.empty(n_local, dtype=torch.int32, device=self.device)
+        self._ck(self.lib.jg_sim_rank(self.h, _ptr(e1), _ptr(e2), n_local, e2.shape[0], row_offset, D, _ptr(rank), _ptr(ties)))
+        return rank, ties
+
+    def spot(self, gesture, content, g_offsets, c_offsets, targets, temp=0.07):
+        self._bind_stream()
+        g, c = self._f32(gesture), self._f32(content)
+        go, co, tg = self._i32(g_offsets), self._i32(c_offsets), self._i32(targets)
+        n = tg.numel()
+        pred = torch.empty(n, dtype=torch.int32, device=self.device)
+        score = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_spot(self.h, _ptr(g), _ptr(c), _ptr(go), _ptr(co), _ptr(tg), n, g.shape[-1], temp, _ptr(pred), _ptr(score)))
+        return pred, score
+
+    def asd(self, query, cand, c_offsets, temp=0.07):
+        self._bind_stream()
+        q, c = self._f32(query), self._f32(cand)
+        co = self._i32(c_offsets)
+        n = q.shape[0]
+        pred = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        self._ck(self.lib.jg_asd(self.h, _ptr(q), _ptr(c), _ptr(co), n, q.shape[-1], temp, _ptr(pred)))
+        return pred
+
+    # ---- profiling
+    def profile(self, on):
+        self._ck(self.lib.jg_profile_enable(self.h, int(bool(on))))
+
+    def profile_reset(self):
+        self._ck(self.lib.jg_profile_reset(self.h))
+
+    def profile_get(self):
+        res = {}
+        for i, name in enumerate(STAGES):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            self._ck(self.lib.jg_profile_get(self.h, i, ctypes.byref(ms), ctypes.byref(n)))
+            res[name] = (ms.value, n.value)
+        return res
+
+    def workspace_bytes(self):
+        return int(self.lib.jg_workspace_bytes(self.h))

@@ -1,0 +1,812 @@
+// libjegal_hip: handle, weight packing and the host-side orchestration of the HIP kernels behind
+// the C ABI of include/jegal_hip.h.  Host code only (no kernels here).
+#include "common.h"
+#include "../../include/jegal_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), fp32 bias
+    f16* wh = nullptr;
+    f16* wl = nullptr;
+    float* bias = nullptr;
+    int N = 0, K = 0;
+};
+struct LNp { float* w = nullptr; float* b = nullptr; };
+
+struct EncLayer { Lin qkv, out, ff1, ff2; LNp n1, n2; };
+
+struct Arena {          // stream-ordered bump allocator over persistent chunks
+    struct Chunk { char* p; size_t cap; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, off = 0;
+    void reset() { cur = 0; off = 0; }
+    size_t total() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
+    void* alloc(size_t bytes, hipError_t* err) {
+        bytes = (bytes + 255) & ~size_t(255);
+        while (cur < chunks.size()) {
+            if (off + bytes <= chunks[cur].cap) { void* r = chunks[cur].p + off; off += bytes; return r; }
+            ++cur; off = 0;
+        }
+        size_t cap = bytes > (size_t(1) << 30) ? bytes : (size_t(1) << 30);
+        char* p = nullptr;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) { *err = e; return nullptr; }
+        chunks.push_back({p, cap});
+        cur = chunks.size() - 1; off = bytes;
+        return p;
+    }
+    void release() { for (auto& c : chunks) hipFree(c.p); chunks.clear(); reset(); }
+};
+
+struct ProfRec { int stage; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct jg_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int precision = JG_PREC_FP16_W2;
+    int chunk = 8;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> wallocs;
+    Arena ws;
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    double prof_ms[JG_ST_COUNT] = {0};
+    int64_t prof_n[JG_ST_COUNT] = {0};
+
+    // GestSync
+    bool gs_ready = false;
+    Lin c1, c2, c3, c4, c5, fc6, ff0, ff2;
+    float* c1_scale255 = nullptr;
+    float* gs_pe = nullptr;
+    EncLayer gs_layers[6];
+    // JEGAL
+    bool jg_ready = false;
+    Lin ip0, ip3, op_rgb, al_g0, al_g2, fu0, fu2, al_c0, al_c2, op_text, op_audio;
+    LNp ip_ln, rgb_norm, text_norm;
+    float* rgb_pe = nullptr;
+    EncLayer rgb_layers[6], text_layers[3];
+    Lin a0, a3, a6, a9, a12, a15;
+    float* feats = nullptr;
+    size_t feats_cap = 0;
+};
+
+namespace {
+
+#define JG_FAIL(h, code, ...) do { char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__); (h)->err = _b; return (code); } while (0)
+#define HIPCHK(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define RET(expr) do { int _r = (expr); if (_r != JG_OK) return _r; } while (0)
+
+// run a launcher under optional event timing
+template <class F>
+int timed(jg_handle* h, int stage, F&& f) {
+    ProfRec r{stage, nullptr, nullptr};
+    if (h->prof) {
+        HIPCHK(h, hipEventCreate(&r.e0));
+        HIPCHK(h, hipEventCreate(&r.e1));
+        HIPCHK(h, hipEventRecord(r.e0, h->stream));
+    }
+    hipError_t e = f();
+    if (e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "kernel launch failed (stage %s): %s", jg_stage_name(stage), hipGetErrorString(e));
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(r.e1, h->stream));
+        h->recs.push_back(r);
+    }
+    return JG_OK;
+}
+
+template <class T>
+int walloc(jg_handle* h, size_t n, T** out) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, n * sizeof(T) + 256));
+    h->wallocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return JG_OK;
+}
+
+template <class T>
+int upload(jg_handle* h, const std::vector<T>& v, T** out) {
+    RET(walloc<T>(h, v.size(), out));
+    HIPCHK(h, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return JG_OK;
+}
+
+template <class T>
+int wsalloc(jg_handle* h, size_t n, T** out) {
+    hipError_t e = hipSuccess;
+    void* p = h->ws.alloc(n * sizeof(T), &e);
+    if (!p) JG_FAIL(h, JG_ERR_HIP, "workspace allocation of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    *out = reinterpret_cast<T*>(p);
+    return JG_OK;
+}
+
+const HostTensor* find(jg_handle* h, const std::string& name) {
+    auto it = h->host.find(name);
+    return it == h->host.end() ? nullptr : &it->second;
+}
+
+int need(jg_handle* h, const std::string& name, int64_t numel, const HostTensor** out) {
+    const HostTensor* t = find(h, name);
+    if (!t) JG_FAIL(h, JG_ERR_WEIGHT, "missing weight '%s' (strict load)", name.c_str());
+    if (t->numel() != numel) JG_FAIL(h, JG_ERR_WEIGHT, "weight '%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel(), (long long)numel);
+    *out = t;
+    return JG_OK;
+}
+
+// [N][K] fp32 -> device fp16 hi (+lo)
+int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, bool split, Lin* L) {
+    std::vector<f16> hi((size_t)N * K), lo;
+    if (split) lo.resize((size_t)N * K);
+    for (size_t i = 0; i < hi.size(); ++i) {
+        const f16 a = (f16)w[i];
+        hi[i] = a;
+        if (split) lo[i] = (f16)(w[i] - (float)a);
+    }
+    L->N = N; L->K = K;
+    RET(upload(h, hi, &L->wh));
+    if (split) RET(upload(h, lo, &L->wl)); else L->wl = nullptr;
+    RET(upload(h, bias, &L->bias));
+    return JG_OK;
+}
+
+int make_linear(jg_handle* h, const std::string& wname, const std::string& bname, int N, int K, Lin* L) {
+    const HostTensor *w, *b;
+    RET(need(h, wname, (int64_t)N * K, &w));
+    RET(need(h, bname, N, &b));
+    return pack_matrix(h, w->v, b->v, N, K, h->precision >= JG_PREC_FP16_W2, L);
+}
+
+int make_ln(jg_handle* h, const std::string& wname, const std::string& bname, int D, LNp* p) {
+    const HostTensor *w, *b;
+    RET(need(h, wname, D, &w));
+    RET(need(h, bname, D, &b));
+    RET(upload(h, w->v, &p->w));
+    RET(upload(h, b->v, &p->b));
+    return JG_OK;
+}
+
+// conv weight [O][I][KT][KH][KW] (+ optional eval BatchNorm) -> [O][Kpad] with k = ((kh*KW+kw)*slot + (kt*I + c)),
+// slot = channels per (kh,kw) position after padding (16 for conv1's 5x3 temporal stack, I otherwise).
+int make_conv(jg_handle* h, const std::string& conv, const std::string& bn, int O, int I, int KT, int KH, int KW,
+              int slot, int kpad, Lin* L) {
+    const HostTensor *w, *b;
+    RET(need(h, conv + ".weight", (int64_t)O * I * KT * KH * KW, &w));
+    RET(need(h, conv + ".bias", O, &b));
+    std::vector<float> s(O, 1.f), shift(b->v);
+    if (!bn.empty()) {
+        const HostTensor *g, *be, *mu, *var;
+        RET(need(h, bn + ".weight", O, &g));
+        RET(need(h, bn + ".bias", O, &be));
+        RET(need(h, bn + ".running_mean", O, &mu));
+        RET(need(h, bn + ".running_var", O, &var));
+        for (int o = 0; o < O; ++o) {
+            s[o] = g->v[o] / std::sqrt(var->v[o] + 1e-5f);
+            shift[o] = (b->v[o] - mu->v[o]) * s[o] + be->v[o];
+        }
+    }
+    const int K = kpad > 0 ? kpad : KH * KW * slot;
+    std::vector<float> p((size_t)O * K, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int c = 0; c < I; ++c)
+            for (int kt = 0; kt < KT; ++kt)
+                for (int kh = 0; kh < KH; ++kh)
+                    for (int kw = 0; kw < KW; ++kw) {
+                        const float v = w->v[((((size_t)o * I + c) * KT + kt) * KH + kh) * KW + kw] * s[o];
+                        p[(size_t)o * K + (size_t)(kh * KW + kw) * slot + kt * I + c] = v;
+                    }
+    return pack_matrix(h, p, shift, O, K, h->precision >= JG_PREC_FP16_W2_ALL, L);
+}
+
+int make_annotated_layer(jg_handle* h, const std::string& p, int D, int Dff, EncLayer* L) {
+    // pack linears.0/1/2 (q,k,v) into one [3D][D] projection (modules.py:108-110)
+    std::vector<float> w((size_t)3 * D * D), b((size_t)3 * D);
+    for (int i = 0; i < 3; ++i) {
+        const HostTensor *wi, *bi;
+        RET(need(h, p + ".self_attn.linears." + std::to_string(i) + ".weight", (int64_t)D * D, &wi));
+        RET(need(h, p + ".self_attn.linears." + std::to_string(i) + ".bias", D, &bi));
+        std::memcpy(&w[(size_t)i * D * D], wi->v.data(), sizeof(float) * D * D);
+        std::memcpy(&b[(size_t)i * D], bi->v.data(), sizeof(float) * D);
+    }
+    RET(pack_matrix(h, w, b, 3 * D, D, h->precision >= JG_PREC_FP16_W2, &L->qkv));
+    RET(make_linear(h, p + ".self_attn.linears.3.weight", p + ".self_attn.linears.3.bias", D, D, &L->out));
+    RET(make_linear(h, p + ".feed_forward.w_1.weight", p + ".feed_forward.w_1.bias", Dff, D, &L->ff1));
+    RET(make_linear(h, p + ".feed_forward.w_2.weight", p + ".feed_forward.w_2.bias", D, Dff, &L->ff2));
+    RET(make_ln(h, p + ".sublayer.0.norm.a_2", p + ".sublayer.0.norm.b_2", D, &L->n1));
+    RET(make_ln(h, p + ".sublayer.1.norm.a_2", p + ".sublayer.1.norm.b_2", D, &L->n2));
+    return JG_OK;
+}
+
+int finalize_gestsync(jg_handle* h) {
+    RET(make_conv(h, "net_vid.conv1", "net_vid.bn1", 64, 3, 5, 7, 7, 16, 0, &h->c1));
+    RET(make_conv(h, "net_vid.conv2", "net_vid.bn2", 128, 64, 1, 5, 5, 64, 0, &h->c2));
+    RET(make_conv(h, "net_vid.conv3", "net_vid.bn3", 256, 128, 1, 3, 3, 128, 0, &h->c3));
+    RET(make_conv(h, "net_vid.conv4", "net_vid.bn4", 256, 256, 1, 3, 3, 256, 0, &h->c4));
+    RET(make_conv(h, "net_vid.conv5", "net_vid.bn5", 256, 256, 1, 3, 3, 256, 0, &h->c5));
+    RET(make_conv(h, "net_vid.fc6", "net_vid.bn6", 512, 256, 1, 4, 4, 256, 0, &h->fc6));
+    RET(upload(h, std::vector<float>(64, 1.0f / 255.0f), &h->c1_scale255));
+    RET(make_linear(h, "ff_vid.0.weight", "ff_vid.0.bias", 512, 512, &h->ff0));
+    RET(make_linear(h, "ff_vid.2.weight", "ff_vid.2.bias", 1024, 512, &h->ff2));
+    const HostTensor* pe;
+    RET(need(h, "pos_encoder.pe", 50 * 512, &pe));
+    RET(upload(h, pe->v, &h->gs_pe));
+    for (int l = 0; l < 6; ++l) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(l);
+        EncLayer* L = &h->gs_layers[l];
+        RET(make_linear(h, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 1536, 512, &L->qkv));
+        RET(make_linear(h, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 512, 512, &L->out));
+        RET(make_linear(h, p + ".linear1.weight", p + ".linear1.bias", 2048, 512, &L->ff1));
+        RET(make_linear(h, p + ".linear2.weight", p + ".linear2.bias", 512, 2048, &L->ff2));
+        RET(make_ln(h, p + ".norm1.weight", p + ".norm1.bias", 512, &L->n1));
+        RET(make_ln(h, p + ".norm2.weight", p + ".norm2.bias", 512, &L->n2));
+    }
+    h->gs_ready = true;
+    return JG_OK;
+}
+
+int finalize_jegal(jg_handle* h) {
+    RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0));
+    RET(make_ln(h, "proj_ip_rgb.1.weight", "proj_ip_rgb.1.bias", 512, &h->ip_ln));
+    RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3));
+    const HostTensor* pe;
+    RET(need(h, "position_rgb.pe", 500 * 512, &pe));
+    RET(upload(h, pe->v, &h->rgb_pe));
+    for (int l = 0; l < 6; ++l) RET(make_annotated_layer(h, "encoder_rgb.layers." + std::to_string(l), 512, 2048, &h->rgb_layers[l]));
+    RET(make_ln(h, "encoder_rgb.norm.a_2", "encoder_rgb.norm.b_2", 512, &h->rgb_norm));
+    RET(make_linear(h, "proj_op_rgb.weight", "proj_op_rgb.bias", 512, 512, &h->op_rgb));
+    for (int l = 0; l < 3; ++l) RET(make_annotated_layer(h, "encoder_text.layers." + std::to_string(l), 768, 3072, &h->text_layers[l]));
+    RET(make_ln(h, "encoder_text.norm.a_2", "encoder_text.norm.b_2", 768, &h->text_norm));
+    RET(make_linear(h, "proj_op_text.weight", "proj_op_text.bias", 256, 768, &h->op_text));
+    RET(make_conv(h, "cnn.0", "cnn.1", 32, 1, 1, 5, 5, 1, 32, &h->a0));
+    RET(make_conv(h, "cnn.3", "cnn.4", 64, 32, 1, 3, 3, 32, 0, &h->a3));
+    RET(make_conv(h, "cnn.6", "cnn.7", 128, 64, 1, 3, 3, 64, 0, &h->a6));
+    RET(make_conv(h, "cnn.9", "cnn.10", 256, 128, 1, 3, 3, 128, 0, &h->a9));
+    RET(make_conv(h, "cnn.12", "cnn.13", 256, 256, 1, 3, 3, 256, 0, &h->a12));
+    RET(make_conv(h, "cnn.15", "", 256, 256, 1, 1, 1, 256, 0, &h->a15));
+    RET(make_linear(h, "proj_op_audio.weight", "proj_op_audio.bias", 256, 256, &h->op_audio));
+    RET(make_linear(h, "proj_op_fusion_content.0.weight", "proj_op_fusion_content.0.bias", 512, 512, &h->fu0));
+    RET(make_linear(h, "proj_op_fusion_content.2.weight", "proj_op_fusion_content.2.bias", 512, 512, &h->fu2));
+    RET(make_linear(h, "proj_op_align_gesture.0.weight", "proj_op_align_gesture.0.bias", 512, 512, &h->al_g0));
+    RET(make_linear(h, "proj_op_align_gesture.2.weight", "proj_op_align_gesture.2.bias", 512, 512, &h->al_g2));
+    RET(make_linear(h, "proj_op_align_content.0.weight", "proj_op_align_content.0.bias", 512, 512, &h->al_c0));
+    RET(make_linear(h, "proj_op_align_content.2.weight", "proj_op_align_content.2.bias", 512, 512, &h->al_c2));
+    h->jg_ready = true;
+    return JG_OK;
+}
+
+// ------------------------------------------------------------------------------------ GEMM helpers
+struct Epi {
+    const float* scale = nullptr;
+    const float* res = nullptr;
+    long ldr = 0;
+    int res_mod = 0;
+    float* out32 = nullptr;
+    f16* out16 = nullptr;
+    long ldc = 0;
+    int relu = 0;
+};
+
+int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda;
+    if (g) a.g = *g;
+    a.Wh = L.wh; a.Wl = L.wl; a.ldw = L.K;
+    a.M = M; a.N = L.N; a.K = L.K;
+    a.scale = e.scale; a.bias = L.bias;
+    a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
+    a.out32 = e.out32; a.out16 = e.out16; a.ldc = e.ldc ? e.ldc : L.N;
+    a.relu = e.relu;
+    const bool conv = g != nullptr;
+    return timed(h, stage, [&] { return launch_gemm(a, conv, h->stream); });
+}
+
+ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW) {
+    ConvGeom g;
+    g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.SH = SH; g.SW = SW; g.PH = PH; g.PW = PW;
+    g.OH = (H + 2 * PH - KH) / SH + 1;
+    g.OW = (W + 2 * PW - KW) / SW + 1;
+    g.cshift = 0;
+    while ((1 << g.cshift) < C) ++g.cshift;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------ GestSync
+constexpr int FH = 270, FW = 480;
+
+// conv stack over `nclip` temporal volumes -> conv_out (nclip*P, 512) fp32, P = T + 2*pad - 4
+int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, long sh, long sw, long sc,
+                  int nclip, int T, int pad, float* conv_out) {
+    const int P = T + 2 * pad - 4;
+    const long NF = (long)nclip * P;
+    f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
+    const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
+    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0);            // 20 x 37
+    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1);           // 10 x 19
+    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1);           // 10 x 10
+    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1);           // 10 x 10
+    RET(wsalloc(h, (size_t)NF * 43 * 78 * 64, &p1));
+    RET(wsalloc(h, (size_t)NF * 20 * 37 * 128, &o2));
+    RET(wsalloc(h, (size_t)NF * 10 * 19 * 256, &o3));
+    RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o4));
+    RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o5));
+    RET(wsalloc(h, (size_t)NF * 4 * 4 * 256, &p5));
+    RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
+    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
+
+    RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
+    Epi e;
+    e.relu = 1;
+    e.scale = src_u8 ? h->c1_scale255 : nullptr;
+    e.out16 = o1;
+    RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
+    e.scale = nullptr;
+    e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
+    e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
+    e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
+    e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream); }));
+    e.out16 = nullptr; e.out32 = conv_out;
+    RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
+    return JG_OK;
+}
+
+// post-norm transformer (gestsync.py:20-21) in place on x32/x16, M = nseq*21 tokens
+int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S) {
+    const int M = nseq * S;
+    f16 *qkv, *att, *hid;
+    RET(wsalloc(h, (size_t)M * 1536, &qkv));
+    RET(wsalloc(h, (size_t)M * 512, &att));
+    RET(wsalloc(h, (size_t)M * 2048, &hid));
+    for (int l = 0; l < 6; ++l) {
+        const EncLayer& L = h->gs_layers[l];
+        Epi e;
+        e.out16 = qkv;
+        RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
+        Epi r;
+        r.res = x32; r.ldr = 512; r.out32 = x32;
+        RET(gemm(h, JG_ST_GEMM, att, 512, M, L.out, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, 512, LN_STD, 0, x32, x16, h->stream); }));
+        Epi f;
+        f.relu = 1; f.out16 = hid;
+        RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.ff1, f));
+        RET(gemm(h, JG_ST_GEMM, hid, 2048, M, L.ff2, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, 512, LN_STD, 0, x32, x16, h->stream); }));
+    }
+    return JG_OK;
+}
+
+int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_feats) {
+    if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
+    if (B <= 0 || T <= 0) JG_FAIL(h, JG_ERR_ARG, "B and T must be positive");
+    if (dtype != JG_U8 && dtype != JG_F32) JG_FAIL(h, JG_ERR_ARG, "frames dtype must be JG_U8 or JG_F32");
+    const int P = T + 20, S = 21;
+    const size_t esz = dtype == JG_U8 ? 1 : 4;
+    const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
+    for (int b0 = 0; b0 < B; b0 += h->chunk) {
+        const int nb = std::min(h->chunk, B - b0);
+        h->ws.reset();
+        float* conv;
+        RET(wsalloc(h, (size_t)nb * P * 512, &conv));
+        const char* src = reinterpret_cast<const char*>(frames) + (size_t)b0 * sb * esz;
+        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, 12, conv));
+        const int nseq = nb * T, M = nseq * S;
+        float* x32; f16 *x16, *hid, *mean16;
+        RET(wsalloc(h, (size_t)M * 512, &x32));
+        RET(wsalloc(h, (size_t)M * 512, &x16));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, x32, x16, h->stream); }));
+        RET(gs_transformer(h, x32, x16, nseq, S));
+        RET(wsalloc(h, (size_t)M * 512, &hid));
+        RET(wsalloc(h, (size_t)nseq * 512, &mean16));
+        Epi f; f.relu = 1; f.out16 = hid;
+        RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_group_mean(hid, nseq, S, 512, mean16, h->stream); }));
+        Epi o; o.out32 = out_feats + (size_t)b0 * T * 1024;
+        RET(gemm(h, JG_ST_GEMM, mean16, 512, nseq, h->ff2, o));
+    }
+    return JG_OK;
+}
+
+int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float* out_conv) {
+    if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
+    if (N <= 0) JG_FAIL(h, JG_ERR_ARG, "N must be positive");
+    const int S = 21;
+    const long sw = 1, sh = FW, st = (long)FH * FW, sc = 25 * st, sb = 3 * sc;
+    const int wchunk = std::max(1, h->chunk * 8);
+    for (int n0 = 0; n0 < N; n0 += wchunk) {
+        const int nb = std::min(wchunk, N - n0);
+        h->ws.reset();
+        float* conv;
+        RET(wsalloc(h, (size_t)nb * S * 512, &conv));
+        RET(gs_conv_stack(h, x + (size_t)n0 * sb, 0, sb, st, sh, sw, sc, nb, 25, 0, conv));
+        if (out_conv)
+            RET(timed(h, JG_ST_MISC, [&] { return launch_transpose_tokens(conv, nb, S, 512, out_conv + (size_t)n0 * 512 * S, h->stream); }));
+        const int M = nb * S;
+        float *x32, *full; f16 *x16, *hid;
+        RET(wsalloc(h, (size_t)M * 512, &x32));
+        RET(wsalloc(h, (size_t)M * 512, &x16));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, x32, x16, h->stream); }));
+        RET(gs_transformer(h, x32, x16, nb, S));
+        RET(wsalloc(h, (size_t)M * 512, &hid));
+        RET(wsalloc(h, (size_t)M * 1024, &full));
+        Epi f; f.relu = 1; f.out16 = hid;
+        RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
+        Epi o; o.out32 = full;
+        RET(gemm(h, JG_ST_GEMM, hid, 512, M, h->ff2, o));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_transpose_tokens(full, nb, S, 1024, out + (size_t)n0 * 1024 * S, h->stream); }));
+    }
+    return JG_OK;
+}
+
+// ------------------------------------------------------------------------------------ JEGAL
+// pre-norm encoder (modules.py:11-59) in place on x32; returns final-norm output in n16
+int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& fin, float* x32, f16* n16,
+                      const float* mask, int B, int S, int D, int Dff) {
+    const int M = B * S, H = 8, dk = D / H;
+    f16 *qkv, *att, *hid;
+    RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
+    RET(wsalloc(h, (size_t)M * D, &att));
+    RET(wsalloc(h, (size_t)M * Dff, &hid));
+    for (int l = 0; l < nl; ++l) {
+        const EncLayer& L = layers[l];
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+        Epi e; e.out16 = qkv;
+        RET(gemm(h, JG_ST_GEMM, n16, D, M, L.qkv, e));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mask, B, S, H, dk, att, h->stream); }));
+        Epi r; r.res = x32; r.ldr = D; r.out32 = x32;
+        RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+        Epi f; f.relu = 1; f.out16 = hid;
+        RET(gemm(h, JG_ST_GEMM, n16, D, M, L.ff1, f));
+        RET(gemm(h, JG_ST_GEMM, hid, Dff, M, L.ff2, r));
+    }
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+    return JG_OK;
+}
+
+int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
+    if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
+    if (B <= 0 || T <= 0 || T > 500) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < T <= 500 (PE table, modules.py:136)");
+    const int M = B * T;
+    f16 *f16in, *t16, *n16, *g16, *a16;
+    float *t32, *x32;
+    RET(wsalloc(h, (size_t)M * 1024, &f16in));
+    RET(wsalloc(h, (size_t)M * 512, &t32));
+    RET(wsalloc(h, (size_t)M * 512, &t16));
+    RET(wsalloc(h, (size_t)M * 512, &x32));
+    RET(wsalloc(h, (size_t)M * 512, &n16));
+    RET(timed(h, JG_ST_MISC, [&] { return launch_cast_f32_f16(feats, f16in, (long)M * 1024, h->stream); }));
+    Epi e; e.out32 = t32;
+    RET(gemm(h, JG_ST_GEMM, f16in, 1024, M, h->ip0, e));
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, nullptr, t16, h->stream); }));
+    Epi p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T; p.out32 = x32;
+    RET(gemm(h, JG_ST_GEMM, t16, 512, M, h->ip3, p));
+    RET(annotated_encoder(h, h->rgb_layers, 6, h->rgb_norm, x32, n16, mask, B, T, 512, 2048));
+    if (!align) {
+        Epi o; o.out32 = out;
+        return gemm(h, JG_ST_GEMM, n16, 512, M, h->op_rgb, o);
+    }
+    RET(wsalloc(h, (size_t)M * 512, &g16));
+    RET(wsalloc(h, (size_t)M * 512, &a16));
+    Epi o1; o1.out16 = g16;
+    RET(gemm(h, JG_ST_GEMM, n16, 512, M, h->op_rgb, o1));
+    Epi o2; o2.relu = 1; o2.out16 = a16;
+    RET(gemm(h, JG_ST_GEMM, g16, 512, M, h->al_g0, o2));
+    Epi o3; o3.out32 = out;
+    return gemm(h, JG_ST_GEMM, a16, 512, M, h->al_g2, o3);
+}
+
+int audio_len(int Tm) {
+    const int h1 = (Tm + 2 - 3) / 2 + 1;
+    return (h1 + 2 - 3) / 2 + 1;
+}
+
+int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) {
+    if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
+    if (B <= 0 || Tm < 4) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and Tm >= 4");
+    const int F = 80;
+    const ConvGeom g3 = geom(Tm, F, 32, 3, 3, 2, 2, 1, 1);
+    const ConvGeom g6 = geom(g3.OH, g3.OW, 64, 3, 3, 2, 2, 1, 1);
+    const ConvGeom g9 = geom(g6.OH, g6.OW, 128, 3, 3, 1, 3, 1, 1);
+    const ConvGeom g12 = geom(g9.OH, g9.OW, 256, 3, 3, 1, 3, 1, 1);
+    const ConvGeom g15 = geom(g12.OH, g12.OW, 256, 1, 1, 1, 3, 0, 0);
+    if (g15.OW != 1) JG_FAIL(h, JG_ERR_ARG, "audio CNN must reduce 80 mel bands to 1");
+    f16 *col, *c0, *c3, *c6, *c9, *c12, *c15;
+    const long M0 = (long)B * Tm * F;
+    RET(wsalloc(h, (size_t)M0 * 32, &col));
+    RET(wsalloc(h, (size_t)M0 * 32, &c0));
+    RET(wsalloc(h, (size_t)B * g3.OH * g3.OW * 64, &c3));
+    RET(wsalloc(h, (size_t)B * g6.OH * g6.OW * 128, &c6));
+    RET(wsalloc(h, (size_t)B * g9.OH * g9.OW * 256, &c9));
+    RET(wsalloc(h, (size_t)B * g12.OH * g12.OW * 256, &c12));
+    RET(wsalloc(h, (size_t)B * g15.OH * 256, &c15));
+    RET(timed(h, JG_ST_MISC, [&] { return launch_im2col_mel(mel, B, Tm, F, col, h->stream); }));
+    Epi e; e.relu = 1;
+    e.out16 = c0; RET(gemm(h, JG_ST_CONV, col, 32, (int)M0, h->a0, e));
+    e.out16 = c3; RET(gemm(h, JG_ST_CONV, c0, 0, B * g3.OH * g3.OW, h->a3, e, &g3));
+    e.out16 = c6; RET(gemm(h, JG_ST_CONV, c3, 0, B * g6.OH * g6.OW, h->a6, e, &g6));
+    e.out16 = c9; RET(gemm(h, JG_ST_CONV, c6, 0, B * g9.OH * g9.OW, h->a9, e, &g9));
+    e.out16 = c12; RET(gemm(h, JG_ST_CONV, c9, 0, B * g12.OH * g12.OW, h->a12, e, &g12));
+    e.relu = 0;
+    e.out16 = c15; RET(gemm(h, JG_ST_CONV, c12, 0, B * g15.OH, h->a15, e, &g15));
+    Epi o; o.out32 = out;
+    return gemm(h, JG_ST_GEMM, c15, 256, B * g15.OH, h->op_audio, o);
+}
+
+int jegal_text_impl(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
+    if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
+    if (B <= 0 || L <= 0) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and L > 0");
+    const int M = B * L;
+    float* x32; f16* n16;
+    RET(wsalloc(h, (size_t)M * 768, &x32));
+    RET(wsalloc(h, (size_t)M * 768, &n16));
+    HIPCHK(h, hipMemcpyAsync(x32, states, (size_t)M * 768 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    RET(annotated_encoder(h, h->text_layers, 3, h->text_norm, x32, n16, mask, B, L, 768, 3072));
+    Epi o; o.out32 = out;
+    return gemm(h, JG_ST_GEMM, n16, 768, M, h->op_text, o);
+}
+
+int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
+    if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
+    if (rows <= 0) JG_FAIL(h, JG_ERR_ARG, "rows must be positive");
+    f16 *x16, *a16, *b16;
+    RET(wsalloc(h, (size_t)rows * 512, &x16));
+    RET(wsalloc(h, (size_t)rows * 512, &a16));
+    RET(wsalloc(h, (size_t)rows * 512, &b16));
+    RET(timed(h, JG_ST_MISC, [&] { return launch_cast_f32_f16(fused, x16, (long)rows * 512, h->stream); }));
+    Epi r; r.relu = 1; r.out16 = a16;
+    RET(gemm(h, JG_ST_GEMM, x16, 512, rows, h->fu0, r));
+    Epi p; p.out16 = b16;
+    RET(gemm(h, JG_ST_GEMM, a16, 512, rows, h->fu2, p));
+    RET(gemm(h, JG_ST_GEMM, b16, 512, rows, h->al_c0, r));
+    Epi o; o.out32 = out;
+    return gemm(h, JG_ST_GEMM, a16, 512, rows, h->al_c2, o);
+}
+
+}  // namespace
+
+// ======================================================================================= C ABI
+extern "C" {
+
+const char* jg_stage_name(int s) {
+    static const char* n[] = {"stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc"};
+    return (s >= 0 && s < JG_ST_COUNT) ? n[s] : "?";
+}
+
+int jg_create(int device, jg_handle** out) {
+    if (!out) return JG_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return JG_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return JG_ERR_HIP;
+    jg_handle* h = new jg_handle();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return JG_ERR_HIP; }
+    h->stream = h->own_stream;
+    *out = h;
+    return JG_OK;
+}
+
+int jg_destroy(jg_handle* h) {
+    if (!h) return JG_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (void* p : h->wallocs) hipFree(p);
+    if (h->feats) hipFree(h->feats);
+    h->ws.release();
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return JG_OK;
+}
+
+const char* jg_last_error(jg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int jg_set_stream(jg_handle* h, void* s) {
+    if (!h) return JG_ERR_ARG;
+    h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own_stream;
+    return JG_OK;
+}
+
+int jg_set_precision(jg_handle* h, int mode) {
+    if (!h) return JG_ERR_ARG;
+    if (mode < JG_PREC_FP16 || mode > JG_PREC_FP16_W2_ALL) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
+    if (h->gs_ready || h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
+    h->precision = mode;
+    return JG_OK;
+}
+
+int jg_set_chunk(jg_handle* h, int c) {
+    if (!h) return JG_ERR_ARG;
+    if (c < 1) JG_FAIL(h, JG_ERR_ARG, "clips_per_chunk must be >= 1");
+    h->chunk = c;
+    return JG_OK;
+}
+
+int jg_sync(jg_handle* h) {
+    if (!h) return JG_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return JG_OK;
+}
+
+int jg_load_tensor(jg_handle* h, const char* name, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!h) return JG_ERR_ARG;
+    if (!name || !data || ndim < 0 || (ndim > 0 && !shape)) JG_FAIL(h, JG_ERR_ARG, "jg_load_tensor: bad arguments");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    t.v.resize((size_t)n);
+    switch (dtype) {
+        case JG_F32: std::memcpy(t.v.data(), data, sizeof(float) * n); break;
+        case JG_F16: { const f16* p = static_cast<const f16*>(data); for (int64_t i = 0; i < n; ++i) t.v[i] = (float)p[i]; } break;
+        case JG_I64: { const int64_t* p = static_cast<const int64_t*>(data); for (int64_t i = 0; i < n; ++i) t.v[i] = (float)p[i]; } break;
+        default: JG_FAIL(h, JG_ERR_ARG, "jg_load_tensor(%s): unsupported dtype %d", name, dtype);
+    }
+    std::string key(name);
+    if (key.rfind("module.", 0) == 0) key = key.substr(7);     // inference_embs.py:113-114
+    h->host[key] = std::move(t);
+    return JG_OK;
+}
+
+int jg_finalize_weights(jg_handle* h, int which) {
+    if (!h) return JG_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (which & 1) RET(finalize_gestsync(h));
+    if (which & 2) RET(finalize_jegal(h));
+    return JG_OK;
+}
+
+int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!frames || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return gestsync_clip_impl(h, frames, dtype, B, T, out);
+}
+
+int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv) {
+    if (!h) return JG_ERR_ARG;
+    if (!x || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return gestsync_windows_impl(h, x, N, out, out_conv);
+}
+
+int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!feats || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return jegal_gestures_impl(h, feats, mask, B, T, align, out);
+}
+
+int jg_audio_len(int Tm) { return audio_len(Tm); }
+
+int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!mel || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return jegal_audio_impl(h, mel, B, Tm, out);
+}
+
+int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!states || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return jegal_text_impl(h, states, mask, B, L, out);
+}
+
+int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {
+    if (!h) return JG_ERR_ARG;
+    if (!seq || !seg || !dst) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return timed(h, JG_ST_MISC, [&] { return launch_segment_mean(seq, D, seg, n, nullptr, dst, dst_ld, dst_col, h->stream); });
+}
+
+int jg_fuse_content(jg_handle* h, const float* fused, int rows, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!fused || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return fuse_content_impl(h, fused, rows, out);
+}
+
+int jg_l2norm(jg_handle* h, const float* in, float* out, int rows, int D) {
+    if (!h) return JG_ERR_ARG;
+    if (!in || !out || D % 4) JG_FAIL(h, JG_ERR_ARG, "bad l2norm arguments");
+    return timed(h, JG_ST_MISC, [&] { return launch_l2norm(in, out, rows, D, h->stream); });
+}
+
+int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_emb) {
+    if (!h) return JG_ERR_ARG;
+    if (!frames || !out_emb) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    if (T > 500) JG_FAIL(h, JG_ERR_ARG, "T must be <= 500");
+    // the (B,T,1024) GestSync features stay on the device in a buffer owned by the handle
+    const size_t need_b = (size_t)B * T * 1024 * sizeof(float);
+    if (need_b > h->feats_cap) {
+        if (h->feats) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->feats)); h->feats = nullptr; h->feats_cap = 0; }
+        HIPCHK(h, hipMalloc(&h->feats, need_b));
+        h->feats_cap = need_b;
+    }
+    RET(gestsync_clip_impl(h, frames, dtype, B, T, h->feats));
+    h->ws.reset();
+    RET(jegal_gestures_impl(h, h->feats, nullptr, B, T, 1, out_emb));
+    return timed(h, JG_ST_MISC, [&] { return launch_l2norm(out_emb, out_emb, B * T, 512, h->stream); });
+}
+
+int jg_pool_mean(jg_handle* h, const float* x, const int32_t* off, int n, int D, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!x || !off || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return timed(h, JG_ST_MISC, [&] { return launch_ragged_mean(x, off, n, D, out, h->stream); });
+}
+
+int jg_sim_rank(jg_handle* h, const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
+                int32_t* rank, int32_t* ties) {
+    if (!h) return JG_ERR_ARG;
+    if (!e1 || !e2 || !rank || !ties) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    if (D % 64 || row_offset < 0 || row_offset + n_local > n_total) JG_FAIL(h, JG_ERR_ARG, "bad sim_rank geometry");
+    return timed(h, JG_ST_MISC, [&] { return launch_sim_rank(e1, e2, n_local, n_total, row_offset, D, rank, ties, h->stream); });
+}
+
+int jg_spot(jg_handle* h, const float* g, const float* c, const int32_t* goff, const int32_t* coff, const int32_t* target,
+            int n, int D, float temp, int32_t* pred, float* score) {
+    if (!h) return JG_ERR_ARG;
+    if (!g || !c || !goff || !coff || !target || !pred || !score) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return timed(h, JG_ST_MISC, [&] { return launch_spot(g, c, goff, coff, target, n, D, temp, pred, score, h->stream); });
+}
+
+int jg_asd(jg_handle* h, const float* q, const float* cand, const int32_t* coff, int n, int D, float temp, int32_t* pred) {
+    if (!h) return JG_ERR_ARG;
+    if (!q || !cand || !coff || !pred) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    return timed(h, JG_ST_MISC, [&] { return launch_asd(q, cand, coff, n, D, temp, pred, h->stream); });
+}
+
+int jg_profile_enable(jg_handle* h, int on) {
+    if (!h) return JG_ERR_ARG;
+    h->prof = on != 0;
+    return JG_OK;
+}
+
+static int prof_collect(jg_handle* h) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+        h->prof_ms[r.stage] += ms;
+        h->prof_n[r.stage] += 1;
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    h->recs.clear();
+    return JG_OK;
+}
+
+int jg_profile_get(jg_handle* h, int stage, double* ms, int64_t* launches) {
+    if (!h) return JG_ERR_ARG;
+    if (stage < 0 || stage >= JG_ST_COUNT) JG_FAIL(h, JG_ERR_ARG, "bad stage");
+    RET(prof_collect(h));
+    if (ms) *ms = h->prof_ms[stage];
+    if (launches) *launches = h->prof_n[stage];
+    return JG_OK;
+}
+
+int jg_profile_reset(jg_handle* h) {
+    if (!h) return JG_ERR_ARG;
+    RET(prof_collect(h));
+    for (int i = 0; i < JG_ST_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return JG_OK;
+}
+
+int64_t jg_workspace_bytes(jg_handle* h) { return h ? (int64_t)h->ws.total() : 0; }
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Shared device/host declarations for libjegal_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Geometry of an NHWC implicit-GEMM convolution (C must be a power of two >= 8).
+struct ConvGeom {
+    int H, W, C;          // input spatial size and channels
+    int OH, OW;           // output spatial size
+    int KH, KW, SH, SW, PH, PW;
+    int cshift;           // log2(C)
+};
+
+// out[m][n] = epi( sum_k A[m][k] * (Wh[n][k] + Wl[n][k]) )
+// epi(v) = relu?( v*scale[n] + bias[n] + res[(m % res_mod)][n] )
+struct GemmArgs {
+    const f16* A;         // plain: row-major [M][lda]; conv: NHWC input
+    long lda;
+    ConvGeom g;
+    const f16* Wh;        // [N][ldw] fp16 (hi part)
+    const f16* Wl;        // [N][ldw] fp16 (lo part, W2 mode) or nullptr
+    long ldw;
+    int M, N, K;
+    const float* scale;   // per-n or nullptr
+    const float* bias;    // per-n or nullptr
+    const float* res;     // fp32 residual or nullptr
+    long ldr;
+    int res_mod;          // residual row = m % res_mod (0: m)
+    float* out32;         // optional fp32 output
+    f16* out16;           // optional fp16 output
+    long ldc;
+    int relu;
+};
+
+enum { LN_STD = 0, LN_ANNOTATED = 1 };
+
+// ---- launchers (each returns hipGetLastError()) -----------------------------------------
+hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
+
+hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
+                               int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
+hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D,
+                                float* x32, f16* x16, hipStream_t s);
+hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,
+                            int relu, float* out32, f16* out16, hipStream_t s);
+hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, hipStream_t s);
+hipError_t launch_group_mean(const f16* in, int groups, int L, int D, f16* out, hipStream_t s);
+hipError_t launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s);
+hipError_t launch_transpose_tokens(const float* in, int N, int L, int D, float* out, hipStream_t s);
+hipError_t launch_l2norm(const float* in, float* out, int rows, int D, hipStream_t s);
+hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, hipStream_t s);
+hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
+                               int dst_ld, int dst_col, hipStream_t s);
+hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
+hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
+hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
+                           int32_t* rank, int32_t* ties, hipStream_t s);
+hipError_t launch_spot(const float* g, const float* c, const int32_t* goff, const int32_t* coff, const int32_t* target,
+                       int n, int D, float temp, int32_t* pred, float* score, hipStream_t s);
+hipError_t launch_asd(const float* q, const float* cand, const int32_t* coff, int n, int D, float temp,
+                      int32_t* pred2, hipStream_t s);

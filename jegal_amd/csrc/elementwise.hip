@@ -1,0 +1,350 @@
+// HBM-bound helper kernels (gfx950): layout changes, pooling, both LayerNorm flavours,
+// L2-normalise, ragged means.  One wave (64 lanes) per row for the row reductions; 16-byte
+// vector accesses wherever the layout allows (guide G13).
+#include "common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Temporal stacking for conv1 (v0 path): S[b][p][h][w][16] = {frame(p+dt)[h][w][c] : dt<5, c<3} + 0
+// frame index = clamp(p + dt - pad, 0, T-1)  (edge padding of inference_embs.py:283; pad=0 for
+// the raw-window path).  u8 sources are kept as exact integers (fp16 holds 0..255 exactly); the
+// 1/255 is applied in fp32 in the conv1 epilogue.
+template <typename SRC>
+__global__ void stack_frames_kernel(const SRC* __restrict__ src, long sb, long st, long sh, long sw, long sc,
+                                    int B, int T, int pad, int H, int W, f16* __restrict__ dst) {
+    const int P = T + 2 * pad - 4;
+    const long total = (long)B * P * H * W;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int w = idx % W;
+        long r = idx / W;
+        const int h = r % H;
+        r /= H;
+        const int p = r % P;
+        const int b = r / P;
+        f16 v[16];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            int f = p + dt - pad;
+            f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+            const SRC* s = src + b * sb + f * st + h * sh + w * sw;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[dt * 3 + c] = (f16)(float)s[c * sc];
+        }
+        v[15] = (f16)0.f;
+        uint4* d = reinterpret_cast<uint4*>(dst + idx * 16);
+        d[0] = *reinterpret_cast<uint4*>(&v[0]);
+        d[1] = *reinterpret_cast<uint4*>(&v[8]);
+    }
+}
+
+hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
+                               int B, int T, int pad, int H, int W, f16* dst, hipStream_t s) {
+    const long total = (long)B * (T + 2 * pad - 4) * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+    if (src_is_u8)
+        hipLaunchKernelGGL(stack_frames_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, sb, st, sh, sw, sc, B, T, pad, H, W, dst);
+    else
+        hipLaunchKernelGGL(stack_frames_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, sb, st, sh, sw, sc, B, T, pad, H, W, dst);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool (1,3,3)/(1,2,2), no padding, NHWC fp16, 8 channels per thread (gestsync.py:42-45,74-77).
+__global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
+    const int cv = C / 8;
+    const long total = (long)N * OH * OW * cv;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = idx % cv;
+        long r = idx / cv;
+        const int ow = r % OW;
+        r /= OW;
+        const int oh = r % OH;
+        const int n = r / OH;
+        f16x8 m;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(in + (((long)n * H + oh * 2 + kh) * W + ow * 2 + kw) * C + c8 * 8);
+                if (kh == 0 && kw == 0) m = v;
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        *reinterpret_cast<f16x8*>(out + idx * 8) = m;
+    }
+}
+
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s) {
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const long total = (long)N * OH * OW * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window gather + positional encoding (gestsync.py:152, windowing of inference_embs.py:488-492):
+// x[(b,i,j)][:] = conv[b][i+j][:] + pe[j][:]   i < Twin, j < L.  conv is (B,P,D) fp32.
+__global__ void window_gather_kernel(const float* __restrict__ conv, const float* __restrict__ pe, int B, int P, int Twin,
+                                     int L, int D, float* __restrict__ x32, f16* __restrict__ x16) {
+    const int dv = D / 4;
+    const long total = (long)B * Twin * L * dv;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int d4 = idx % dv;
+        long r = idx / dv;
+        const int j = r % L;
+        r /= L;
+        const int i = r % Twin;
+        const int b = r / Twin;
+        f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + i + j) * D + d4 * 4);
+        v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
+        *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
+        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
+    }
+}
+
+hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D,
+                                float* x32, f16* x16, hipStream_t s) {
+    const long total = (long)B * Twin * L * (D / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, x32, x16);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm, one wave per row, fp32 statistics.
+//   LN_STD       : nn.LayerNorm   (x-mean)/sqrt(var_biased+1e-5)*w+b          (gestsync.py:20, jegal.py:26)
+//   LN_ANNOTATED : modules.py:32-35  w*(x-mean)/(std_unbiased+1e-6)+b
+// D = 64*4*V (V = 2 for 512, 3 for 768).
+template <int V>
+__global__ void layernorm_kernel(const float* in, const float* __restrict__ w, const float* __restrict__ b,
+                                 int rows, int flavour, int relu, float* out32, f16* __restrict__ out16) {
+    constexpr int D = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = in + row * D;
+    f32x4 v[V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(x + (i * 64 + lane) * 4);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) * (1.f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        v[i] -= mean;
+        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    sq = wave_sum(sq);
+    float inv;
+    if (flavour == LN_STD) inv = 1.f / sqrtf(sq * (1.f / D) + 1e-5f);
+    else inv = 1.f / (sqrtf(sq * (1.f / (D - 1))) + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + col);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + col);
+        f32x4 y = v[i] * inv * ww + bb;
+        if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        if (out32) *reinterpret_cast<f32x4*>(out32 + row * D + col) = y;
+        if (out16) {
+            f16x4 h = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
+            *reinterpret_cast<f16x4*>(out16 + row * D + col) = h;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,
+                            int relu, float* out32, f16* out16, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int grid = (rows + 3) / 4;
+    if (D == 512) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, in, w, b, rows, flavour, relu, out32, out16);
+    else if (D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, in, w, b, rows, flavour, relu, out32, out16);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mean over groups of L consecutive rows (fp16 in, fp32 sum, fp16 out): the mean(-1) of
+// inference_embs.py:511 moved in front of ff_vid.2 (it commutes with the Linear).
+__global__ void group_mean_kernel(const f16* __restrict__ in, int groups, int L, int D, f16* __restrict__ out) {
+    const int dv = D / 8;
+    const long total = (long)groups * dv;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int d8 = idx % dv;
+        const long g = idx / dv;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < L; ++j) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(in + (g * L + j) * D + d8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+        f16x8 o;
+        const float inv = 1.f / L;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] * inv);
+        *reinterpret_cast<f16x8*>(out + idx * 8) = o;
+    }
+}
+
+hipError_t launch_group_mean(const f16* in, int groups, int L, int D, f16* out, hipStream_t s) {
+    const long total = (long)groups * (D / 8);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, groups, L, D, out);
+    return hipGetLastError();
+}
+
+__global__ void cast_kernel(const float* __restrict__ in, f16* __restrict__ out, long n4) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + idx * 4);
+        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        *reinterpret_cast<f16x4*>(out + idx * 4) = h;
+    }
+}
+
+hipError_t launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const long n4 = n / 4;   // all call sites have n % 4 == 0
+    const int grid = (int)((n4 + 255) / 256 < 65536 * 4 ? (n4 + 255) / 256 : 65536 * 4);
+    hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+
+// (N, L, D) -> (N, D, L): the .transpose(1,2) of gestsync.py:156 for the drop-in forward_vid output.
+__global__ void transpose_tokens_kernel(const float* __restrict__ in, int L, int D, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const long n = blockIdx.z;
+    const int d0 = blockIdx.x * 32, l0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int l = l0 + r, d = d0 + threadIdx.x;
+        tile[r][threadIdx.x] = (l < L && d < D) ? in[(n * L + l) * D + d] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int d = d0 + r, l = l0 + threadIdx.x;
+        if (d < D && l < L) out[(n * D + d) * L + l] = tile[threadIdx.x][r];
+    }
+}
+
+hipError_t launch_transpose_tokens(const float* in, int N, int L, int D, float* out, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_tokens_kernel, dim3((D + 31) / 32, (L + 31) / 32, N), dim3(32, 8), 0, s, in, L, D, out);
+    return hipGetLastError();
+}
+
+// F.normalize(p=2, dim=-1, eps=1e-12): x / max(||x||, eps)  (inference_embs.py:631,635). One wave per row.
+__global__ void l2norm_kernel(const float* in, float* out, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = in + row * D;
+    float sq = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+        sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+        v.x /= nrm; v.y /= nrm; v.z /= nrm; v.w /= nrm;
+        *reinterpret_cast<f32x4*>(out + row * D + c) = v;
+    }
+}
+
+hipError_t launch_l2norm(const float* in, float* out, int rows, int D, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, out, rows, D);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// First audio conv (jegal.py:42, Conv2d(1,32,5,pad 2)) as im2col: out[(b,t,f)][32] = 25 taps + 7 zeros.
+__global__ void im2col_mel_kernel(const float* __restrict__ mel, int B, int Tm, int F, f16* __restrict__ out) {
+    const long total = (long)B * Tm * F;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int f = idx % F;
+        long r = idx / F;
+        const int t = r % Tm;
+        const int b = r / Tm;
+        f16 v[32];
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const int tt = t + kh - 2, ff = f + kw - 2;
+                float x = 0.f;
+                if (tt >= 0 && tt < Tm && ff >= 0 && ff < F) x = mel[((long)b * Tm + tt) * F + ff];
+                v[kh * 5 + kw] = (f16)x;
+            }
+#pragma unroll
+        for (int e = 25; e < 32; ++e) v[e] = (f16)0.f;
+        uint4* d = reinterpret_cast<uint4*>(out + idx * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<uint4*>(&v[q * 8]);
+    }
+}
+
+hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, hipStream_t s) {
+    const long total = (long)B * Tm * F;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(im2col_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mel, B, Tm, F, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ragged word pooling (jegal.py:174-180,189-195): dst[seg.dst][col..col+D) = mean(seq[seg.start : seg.end]).
+// seg = int32 triplets (start_row, end_row_exclusive, dst_row).  One wave per segment.
+__global__ void segment_mean_kernel(const float* __restrict__ seq, int D, const int32_t* __restrict__ seg, int n,
+                                    f16* __restrict__ dst16, float* __restrict__ dst32, int dst_ld, int dst_col) {
+    const int lane = threadIdx.x & 63;
+    const int sidx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sidx >= n) return;
+    const int s0 = seg[sidx * 3], s1 = seg[sidx * 3 + 1], dr = seg[sidx * 3 + 2];
+    const float inv = 1.f / (float)(s1 - s0);
+    for (int c = lane; c < D; c += 64) {
+        float acc = 0.f;
+        for (int r = s0; r < s1; ++r) acc += seq[(long)r * D + c];
+        const float m = (s1 - s0 > 1) ? acc * inv : acc;
+        if (dst16) dst16[(long)dr * dst_ld + dst_col + c] = (f16)m;
+        if (dst32) dst32[(long)dr * dst_ld + dst_col + c] = m;
+    }
+}
+
+hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
+                               int dst_ld, int dst_col, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((n + 3) / 4), dim3(256), 0, s, seq, D, seg, n, dst16, dst32, dst_ld, dst_col);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_f16(f16* p, long n, hipStream_t s) {
+    return hipMemsetAsync(p, 0, n * sizeof(f16), s);
+}
+
+// Temporal mean of ragged (rows,D) blocks: out[i] = mean(x[offsets[i]:offsets[i+1]])
+// (evaluate_retrieval.py:30-31, evaluate_asd.py:31,35).  One wave per (clip, 64-col group).
+__global__ void ragged_mean_kernel(const float* __restrict__ x, const int32_t* __restrict__ off, int n, int D, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int s0 = off[i], s1 = off[i + 1];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = s0; r < s1; ++r) acc += x[(long)r * D + c];
+        out[(long)i * D + c] = acc / (float)(s1 - s0);
+    }
+}
+
+hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ragged_mean_kernel, dim3(n), dim3(256), 0, s, x, offsets, n, D, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,94 @@
+"""Task metrics on the GPU (evaluation/evaluate_{retrieval,spotting,asd}.py of the reference).
+
+The N x N similarity matrix is never materialised: ``jg_sim_rank`` counts, per query row, the
+gallery rows that beat / tie the diagonal (exact-fp32 MFMA), which is all ``compute_metrics``
+(evaluate_retrieval.py:51-65) uses.  With ``torch.distributed`` initialised, queries are sharded
+across ranks (contiguous blocks, the --rank/--nshard rule of extract_gestsync_feats.py:366-370) and
+the gallery is assembled with one all-gather (RCCL over xGMI on MI355X).
+"""
+import ast
+import math
+
+import numpy as np
+import torch
+
+from ._lib import Engine
+from . import dist as jdist
+
+
+def _offsets(mats):
+    off = np.zeros(len(mats) + 1, np.int32)
+    off[1:] = np.cumsum([m.shape[0] for m in mats])
+    return off
+
+
+def video_level(engine, mats):
+    """Temporal mean per clip (evaluate_retrieval.py:30-31): list of (T_i,512) -> (N,512) device."""
+    cat = torch.as_tensor(np.concatenate([np.asarray(m, np.float32) for m in mats], 0))
+    return engine.pool_mean(cat, _offsets(mats))
+
+
+def metrics_from_ranks(rank, ties):
+    """Rebuild the reference's `ind` vector (one entry per tied position) and its statistics."""
+    rank = np.asarray(rank, np.int64)
+    ties = np.asarray(ties, np.int64)
+    ind = np.concatenate([np.arange(r, r + t) for r, t in zip(rank, ties)]) if len(rank) else np.zeros(0, np.int64)
+    n = len(ind)
+    out = {f"R{k}": float(np.sum(ind < k)) / n for k in (1, 5, 10, 25, 50)}
+    out["MR"] = float(np.median(ind) + 1)
+    return out
+
+
+def retrieval_metrics(emb1, emb2, engine=None):
+    """get_similarity_matrix + compute_metrics (evaluate_retrieval.py:38-65) for query set emb1
+    against gallery emb2 (both (N,512), un-normalised video-level means).  Sharded over ranks when
+    torch.distributed is initialised: every rank passes ITS contiguous block of rows."""
+    eng = engine or Engine.get()
+    e1 = eng.l2norm(torch.as_tensor(np.asarray(emb1, np.float32)) if not isinstance(emb1, torch.Tensor) else emb1)
+    e2 = eng.l2norm(torch.as_tensor(np.asarray(emb2, np.float32)) if not isinstance(emb2, torch.Tensor) else emb2)
+    if jdist.world_size() > 1:
+        gallery, row_offset = jdist.all_gather_rows(e2)
+    else:
+        gallery, row_offset = e2, 0
+    rank, ties = eng.sim_rank(e1, gallery, row_offset)
+    if jdist.world_size() > 1:
+        rank, _ = jdist.all_gather_rows(rank.to(torch.int32).reshape(-1, 1))
+        ties, _ = jdist.all_gather_rows(ties.to(torch.int32).reshape(-1, 1))
+    return metrics_from_ranks(rank.flatten().cpu().numpy(), ties.flatten().cpu().numpy())
+
+
+def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, frame_thresh=9, engine=None):
+    """get_spotting_acc (evaluate_spotting.py:59-90).  ``targets`` are word indices (the reference
+    looks the target boundary up in the clip's list, :70) or [word,start,end] boundaries."""
+    eng = engine or Engine.get()
+    wbs = [ast.literal_eval(w) if isinstance(w, str) else w for w in word_boundaries]
+    tidx = []
+    for wb, t in zip(wbs, targets):
+        if isinstance(t, str):
+            t = ast.literal_eval(t)
+        tidx.append(wb.index(t) if isinstance(t, (list, tuple)) else int(t))
+    g = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in gestures], 0))
+    c = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in contents], 0))
+    pred, score = eng.spot(g, c, _offsets(gestures), _offsets(contents), tidx)
+    pred, score = pred.cpu().numpy(), score.cpu().numpy()
+    correct = 0
+    for i, (wb, t) in enumerate(zip(wbs, tidx)):
+        s = max(0, wb[t][1] - frame_thresh)
+        e = wb[t][2] + frame_thresh
+        if s <= pred[i] <= e and score[i] >= thresh:
+            correct += 1
+    total = len(wbs)
+    if jdist.world_size() > 1:
+        tot = jdist.all_reduce_sum(torch.tensor([correct, total], dtype=torch.int64, device=eng.device))
+        correct, total = int(tot[0]), int(tot[1])
+    return 100.0 * correct / total
+
+
+def asd_accuracy(query_content, candidate_gestures, engine=None):
+    """evaluate_asd.py:94-113: query_content (N,512) video-level; candidate_gestures = list of (P_i,512)
+    with the positive at index 0.  Returns accuracies for 2/4/6 speakers."""
+    eng = engine or Engine.get()
+    cand = torch.as_tensor(np.concatenate([np.asarray(c, np.float32) for c in candidate_gestures], 0))
+    pred = eng.asd(torch.as_tensor(np.asarray(query_content, np.float32)), cand, _offsets(candidate_gestures)).cpu().numpy()
+    n = max(1, pred.shape[0])
+    return tuple(float(np.sum(pred[:, k] == 0)) / n for k in range(3))
