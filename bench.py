@@ -36,7 +36,7 @@ def cpu_baseline(clip_u8, n_windows=24):
     gesture branch; extrapolated to a whole clip."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import jegal_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)     # more threads than this slows the small JEGAL matmuls down
     torch.set_num_threads(cores)
     gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
     jsd = O.tensors(synth.jegal_state_dict())

@@ -39,7 +39,8 @@ enum {
 int jg_create(int device, jg_handle** out);
 int jg_destroy(jg_handle* h);
 const char* jg_last_error(jg_handle* h);
-/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy default
+ * stream.  Until this is called the handle uses a private non-blocking stream. */
 int jg_set_stream(jg_handle* h, void* hip_stream);
 int jg_set_precision(jg_handle* h, int mode);
 /* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */

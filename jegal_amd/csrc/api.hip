@@ -621,7 +621,7 @@ const char* jg_last_error(jg_handle* h) { return h ? h->err.c_str() : "null hand
 
 int jg_set_stream(jg_handle* h, void* s) {
     if (!h) return JG_ERR_ARG;
-    h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own_stream;
+    h->stream = reinterpret_cast<hipStream_t>(s);   // NULL is the legacy default stream, used as such
     return JG_OK;
 }
 

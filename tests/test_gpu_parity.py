@@ -84,7 +84,7 @@ def test_clip_features_match_reference_golden(models, golden_dir):
     assert rel(feats_f32, g["feats"]) < TOL
     # drop-in window path == de-duplicated clip path (size-independent property)
     win = gs.forward_vid(x.cuda()).mean(-1)
-    assert rel(win, feats_f32) < 2e-4
+    assert rel(win, feats_f32) < 5e-4
 
 
 def _gesture_inputs():
