@@ -45,6 +45,8 @@ int jg_set_stream(jg_handle* h, void* hip_stream);
 int jg_set_precision(jg_handle* h, int mode);
 /* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */
 int jg_set_chunk(jg_handle* h, int clips_per_chunk);
+/* tuning/debug switches: "conv1_direct" (1 default: fused u8 conv1 kernel; 0: stack + implicit GEMM) */
+int jg_set_option(jg_handle* h, const char* name, int value);
 int jg_sync(jg_handle* h);
 
 /* ---- weights: replaces model.load_state_dict(sd) (inference_embs.py:92-119,
@@ -61,6 +63,9 @@ int jg_finalize_weights(jg_handle* h, int which);
  * (inference_embs.py:488-492) -> forward_vid -> mean(-1) (inference_embs.py:511) -> (B,T,1024) fp32.
  * The conv stack runs once over the padded clip (window de-duplication, exact). */
 int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, int T, float* out_feats);
+/* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,
+ * pad = temporal edge padding (12 for clips, 0 for a raw 25-frame window) -> out (B*(T+2*pad-4),43,78,64) fp16 NHWC. */
+int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16);
 /* Drop-in for GestSync.forward_vid(x, return_feats) (gestsync.py:148-162): x (N,3,25,270,480) fp32
  * -> out (N,1024,21) fp32, optional out_conv (N,512,21) fp32 (NULL to skip). */
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv);

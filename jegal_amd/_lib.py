@@ -25,11 +25,13 @@ _SIGS = {
     "jg_set_stream": [_P, _P],
     "jg_set_precision": [_P, _I],
     "jg_set_chunk": [_P, _I],
+    "jg_set_option": [_P, ctypes.c_char_p, _I],
     "jg_sync": [_P],
     "jg_load_tensor": [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I, _I],
     "jg_finalize_weights": [_P, _I],
     "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
+    "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
@@ -132,6 +134,9 @@ class Engine:
     def set_precision(self, mode):
         self._ck(self.lib.jg_set_precision(self.h, mode))
 
+    def set_option(self, name, value):
+        self._ck(self.lib.jg_set_option(self.h, name.encode(), int(value)))
+
     def set_chunk(self, clips):
         self._ck(self.lib.jg_set_chunk(self.h, int(clips)))
 
@@ -181,6 +186,15 @@ class Engine:
             raise ValueError(f"frames must be (B,T,270,480,3), got {tuple(frames.shape)}")
         out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
+        return out
+
+    def debug_conv1_pool(self, frames_u8, pad):
+        """conv1+BN+ReLU+maxpool only: (B,T,270,480,3) u8 -> (B*(T+2*pad-4),43,78,64) fp16 NHWC."""
+        self._bind_stream()
+        frames_u8 = frames_u8.to(self.device).contiguous()
+        B, T = frames_u8.shape[:2]
+        out = torch.empty((B * (T + 2 * pad - 4), 43, 78, 64), dtype=torch.float16, device=self.device)
+        self._ck(self.lib.jg_debug_conv1_pool(self.h, _ptr(frames_u8), B, T, pad, _ptr(out)))
         return out
 
     def gestsync_windows(self, x, return_feats=False):

@@ -62,6 +62,7 @@ struct jg_handle {
     std::string err;
     int precision = JG_PREC_FP16_W2;
     int chunk = 8;
+    bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     std::map<std::string, HostTensor> host;
     std::vector<void*> wallocs;
     Arena ws;
@@ -74,6 +75,7 @@ struct jg_handle {
     bool gs_ready = false;
     Lin c1, c2, c3, c4, c5, fc6, ff0, ff2;
     float* c1_scale255 = nullptr;
+    f16* c1_direct = nullptr;      // conv1 weights, slot-major [49][64][16] for the direct kernel
     float* gs_pe = nullptr;
     EncLayer gs_layers[6];
     // JEGAL
@@ -240,6 +242,14 @@ int finalize_gestsync(jg_handle* h) {
     RET(make_conv(h, "net_vid.conv5", "net_vid.bn5", 256, 256, 1, 3, 3, 256, 0, &h->c5));
     RET(make_conv(h, "net_vid.fc6", "net_vid.bn6", 512, 256, 1, 4, 4, 256, 0, &h->fc6));
     RET(upload(h, std::vector<float>(64, 1.0f / 255.0f), &h->c1_scale255));
+    {   // slot-major copy of the packed conv1 panel for conv1_direct_kernel: Wd[s][o][e] = W[o][s*16+e]
+        std::vector<f16> hostw((size_t)64 * 784), wd((size_t)49 * 64 * 16);
+        HIPCHK(h, hipMemcpy(hostw.data(), h->c1.wh, hostw.size() * sizeof(f16), hipMemcpyDeviceToHost));
+        for (int s = 0; s < 49; ++s)
+            for (int o = 0; o < 64; ++o)
+                for (int e = 0; e < 16; ++e) wd[((size_t)s * 64 + o) * 16 + e] = hostw[(size_t)o * 784 + s * 16 + e];
+        RET(upload(h, wd, &h->c1_direct));
+    }
     RET(make_linear(h, "ff_vid.0.weight", "ff_vid.0.bias", 512, 512, &h->ff0));
     RET(make_linear(h, "ff_vid.2.weight", "ff_vid.2.bias", 1024, 512, &h->ff2));
     const HostTensor* pe;
@@ -346,15 +356,21 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o4));
     RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o5));
     RET(wsalloc(h, (size_t)NF * 4 * 4 * 256, &p5));
-    RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
-
-    RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
     Epi e;
     e.relu = 1;
-    e.scale = src_u8 ? h->c1_scale255 : nullptr;
-    e.out16 = o1;
-    RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+    const bool direct = src_u8 && sc == 1 && sw == 3 && sh == (long)FW * 3 && st == (long)FH * FW * 3 && sb == (long)T * st && h->conv1_direct;
+    if (direct) {
+        // u8 HWC video: conv1 straight from the frames, the temporal stack lives only in LDS
+        RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
+                                                                   h->c1_scale255, h->c1.bias, o1, h->stream); }));
+    } else {
+        RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
+        RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
+        e.scale = src_u8 ? h->c1_scale255 : nullptr;
+        e.out16 = o1;
+        RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+    }
     RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
@@ -640,6 +656,12 @@ int jg_set_chunk(jg_handle* h, int c) {
     return JG_OK;
 }
 
+int jg_set_option(jg_handle* h, const char* name, int value) {
+    if (!h || !name) return JG_ERR_ARG;
+    if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
+    JG_FAIL(h, JG_ERR_ARG, "unknown option '%s'", name);
+}
+
 int jg_sync(jg_handle* h) {
     if (!h) return JG_ERR_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -677,6 +699,30 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, 
     if (!h) return JG_ERR_ARG;
     if (!frames || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return gestsync_clip_impl(h, frames, dtype, B, T, out);
+}
+
+int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16) {
+    if (!h) return JG_ERR_ARG;
+    if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
+    if (!frames_u8 || !out_f16 || B <= 0 || T + 2 * pad < 5) JG_FAIL(h, JG_ERR_ARG, "bad arguments");
+    h->ws.reset();
+    const int P = T + 2 * pad - 4;
+    const long NF = (long)B * P;
+    f16* o1;
+    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
+    if (h->conv1_direct) {
+        RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
+                                                                   h->c1_scale255, h->c1.bias, o1, h->stream); }));
+    } else {
+        f16* S;
+        RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
+        const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
+        RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(frames_u8, 1, sb, st, sh, sw, 1, B, T, pad, FH, FW, S, h->stream); }));
+        const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);
+        Epi e; e.relu = 1; e.scale = h->c1_scale255; e.out16 = o1;
+        RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+    }
+    return timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, static_cast<f16*>(out_f16), (int)NF, 88, 158, 64, h->stream); });
 }
 
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv) {

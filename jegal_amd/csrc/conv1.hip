@@ -1,2 +1,190 @@
-// conv1 fused kernel lands here (v1); v0 uses stack_frames + implicit GEMM + maxpool.
+// conv1 of the GestSync VGG stack, direct from uint8 video frames (gfx950).
+//
+//   Conv3d(3->64, k(5,7,7), s(1,3,3)) + BatchNorm(eval) + ReLU          (gestsync.py:36-41, 308-316)
+//   evaluated ONCE per padded-clip position p (window de-duplication).
+//
+// Formulation: the 5 input frames of a position are treated as 15 channels ("temporal stack",
+// padded to a 16-element = 32-byte pixel slot), so K = 49 (kh,kw) slots x 16 = 784 and one
+// v_mfma_f32_32x32x16_f16 k-step is exactly one slot.  Nothing is materialised in HBM: the stack
+// exists only as an LDS tile built from the raw u8 frames.
+//
+// Workgroup = 8 waves on one CU (2 per SIMD):
+//   waves 0-3  MFMA waves.  Each keeps the complete K=784 weight panel of 32 output channels in
+//              196 VGPRs for the whole kernel (weights are the MFMA A operand, never re-read), and
+//              per tile computes two 32-position x 32-channel blocks: per k-step ONE ds_read_b128
+//              (the patch fragment, MFMA B operand) feeds one MFMA.
+//   waves 4-7  loader waves.  They read the 5 source frames of the next tile straight from the
+//              u8 HWC video (12-byte = 4-pixel groups, dword loads), convert u8 -> fp16 exactly
+//              (0..255 are exact in fp16; the 1/255 is applied in fp32 in the epilogue) and write the
+//              32-byte pixel slots into the other LDS buffer.  Their VALU/VMEM work overlaps the MFMA
+//              waves' matrix work on the same SIMDs.
+// Tile = 4 conv rows x 32 conv cols of one position: 16 input rows x 100 pixels x 32 B = 51,200 B,
+// double buffered (102,400 B LDS), one barrier per tile.  Persistent grid, one workgroup per CU,
+// tiles of one position are processed by neighbouring workgroups at the same time (its 5 frames =
+// 1.9 MB stay in the XCD L2s; a frame is re-read for 5 positions).
+// LDS swizzle: the two 16-B halves of pixel slot x are swapped when (x/24)&1 -- lanes r and r+8 of a
+// ds_read_b128 lane group read pixels 24 apart and would otherwise hit the same banks (2-way).
 #include "common.h"
+
+struct Conv1Args {
+    const uint8_t* src;   // [nclip][T][270][480][3]
+    int nclip, T, pad, P;
+    const f16* Wd;        // [49][64][16]  BN-folded weights, slot-major
+    const float* scale;   // [64] or nullptr (1/255 for u8 sources)
+    const float* shift;   // [64]
+    f16* out;             // [nclip*P][88][158][64]
+    long ntiles;
+};
+
+namespace {
+constexpr int IH = 270, IW = 480, OH = 88, OW = 158;
+constexpr int TROWS = 16, TW = 100, SLOT = 32;
+constexpr int TILE_BYTES = TROWS * TW * SLOT;          // 51200
+constexpr int ROW_TILES = 22, COL_TILES = 5, TILES_PER_POS = ROW_TILES * COL_TILES;
+}
+
+__global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_mfma = wave < 4;
+
+    // ---- MFMA-wave state
+    const int chalf = wave & 1, mb0 = (wave >> 1) & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f16x8 wreg[49];
+    int loff[7];
+    if (is_mfma) {
+#pragma unroll
+        for (int s = 0; s < 49; ++s)
+            wreg[s] = *reinterpret_cast<const f16x8*>(a.Wd + ((long)(s * 64 + chalf * 32 + r) * 16 + 8 * h));
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            const int x = 3 * r + kw;
+            loff[kw] = x * SLOT + 16 * (h ^ ((x / 24) & 1));
+        }
+    }
+    const int ltid = tid - 256;
+
+    auto fill = [&](long tile, char* buf) {
+        const long nf = tile / TILES_PER_POS;
+        const int rem = (int)(tile - nf * TILES_PER_POS);
+        const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+        const int b = (int)(nf / a.P), p = (int)(nf - (long)b * a.P);
+        const uint8_t* fb[5];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            int f = p + dt - a.pad;
+            f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
+            fb[dt] = a.src + ((long)b * a.T + f) * (IH * IW * 3);
+        }
+        for (int item = ltid; item < TROWS * 25; item += 256) {
+            const int row = item / 25, g = item - row * 25;
+            const int ih = rt * 12 + row;
+            const int px = j * 96 + 4 * g;
+            uint32_t w[5][3];
+            if (px < IW && ih < IH) {
+                const long off = ((long)ih * IW + px) * 3;
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) {
+                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb[dt] + off);
+                    w[dt][0] = s[0]; w[dt][1] = s[1]; w[dt][2] = s[2];
+                }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) { w[dt][0] = 0; w[dt][1] = 0; w[dt][2] = 0; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f16 e[16];
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int bi = 3 * q + c;
+                        e[dt * 3 + c] = (f16)(float)((w[dt][bi >> 2] >> ((bi & 3) * 8)) & 0xffu);
+                    }
+                e[15] = (f16)0.f;
+                const int x = 4 * g + q;
+                const int f = (x / 24) & 1;
+                char* dst = buf + (row * TW + x) * SLOT;
+                *reinterpret_cast<uint4*>(dst + 16 * f) = *reinterpret_cast<uint4*>(&e[0]);
+                *reinterpret_cast<uint4*>(dst + 16 * (f ^ 1)) = *reinterpret_cast<uint4*>(&e[8]);
+            }
+        }
+    };
+
+    if (!is_mfma && (long)blockIdx.x < a.ntiles) fill(blockIdx.x, smem);
+
+    int it = 0;
+    for (long tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
+        __syncthreads();
+        char* cur = smem + (it & 1) * TILE_BYTES;
+        if (!is_mfma) {
+            const long nxt = tile + gridDim.x;
+            if (nxt < a.ntiles) fill(nxt, smem + ((it + 1) & 1) * TILE_BYTES);
+        } else {
+            const long nf = tile / TILES_PER_POS;
+            const int rem = (int)(tile - nf * TILES_PER_POS);
+            const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int mb = mb0 + 2 * q;
+                const char* base = cur + 3 * mb * (TW * SLOT);
+                f32x16 acc;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 7; ++kw) {
+                        const f16x8 bfrag = *reinterpret_cast<const f16x8*>(base + kh * (TW * SLOT) + loff[kw]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[kh * 7 + kw], bfrag, acc, 0, 0, 0);
+                    }
+                // D[i][jj]: jj = lane&31 -> position, i = (x&3) + 8*(x>>2) + 4*h -> channel within the half
+                const int oh = rt * 4 + mb, ow = j * 32 + r;
+                if (ow < OW) {
+                    const int cb = chalf * 32 + 4 * h;
+                    f16* o = a.out + (((long)nf * OH + oh) * OW + ow) * 64 + cb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        if (a.scale) v *= *reinterpret_cast<const f32x4*>(a.scale + cb + 8 * g);
+                        v += *reinterpret_cast<const f32x4*>(a.shift + cb + 8 * g);
+                        f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
+                        *reinterpret_cast<f16x4*>(o + 8 * g) = hv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, const float* scale,
+                               const float* shift, f16* out, hipStream_t s) {
+    static int num_cu = 0;
+    static bool attr_set = false;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return e;
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    Conv1Args a;
+    a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
+    a.Wd = Wd; a.scale = scale; a.shift = shift; a.out = out;
+    a.ntiles = (long)nclip * a.P * TILES_PER_POS;
+    if (a.ntiles <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(a.ntiles < num_cu ? a.ntiles : num_cu);
+    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), 2 * TILE_BYTES, s, a);
+    return hipGetLastError();
+}

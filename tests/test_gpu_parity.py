@@ -63,6 +63,32 @@ def test_strict_load_rejects_missing_key(engine):
     e2.close()
 
 
+def test_conv1_pool_kernel(models, golden_dir, oracle_sd):
+    """conv1+BN+ReLU+maxpool: fused u8 kernel and the stack+implicit-GEMM formulation, against the
+    reference golden slice and the full oracle tensor."""
+    gs, _ = models
+    gsd, _ = oracle_sd
+    g = np.load(os.path.join(golden_dir, "gestsync_clip.npz"))
+    frames = synth.synth_frames(int(g["seed"]), 1, int(g["T"]))[0]
+    f01 = O.pad_clip(torch.from_numpy(frames.astype(np.float32) / np.float32(255.0)))
+    with torch.no_grad():
+        ref = O.vgg_vid(gsd, f01.permute(3, 0, 1, 2).unsqueeze(0)[:, :, :9], upto="conv1")[0]     # (64,5,43,78)
+    ref = ref.permute(1, 2, 3, 0).numpy()                                                          # (5,43,78,64)
+    outs = {}
+    for direct in (1, 0):
+        gs.engine.set_option("conv1_direct", direct)
+        out = gs.engine.debug_conv1_pool(torch.from_numpy(frames)[None].cuda(), 12).float().cpu().numpy()
+        outs[direct] = out
+        assert out.shape == (26, 43, 78, 64)
+        assert rel(out[0].transpose(2, 0, 1)[:, ::6, ::6], g["conv1_pool_t0"]) < TOL
+        assert rel(out[:5], ref) < TOL, f"direct={direct}"
+        print(f"conv1 direct={direct}: rel {rel(out[:5], ref):.3e} max-abs {np.abs(out[:5] - ref).max():.3e}")
+    gs.engine.set_option("conv1_direct", 1)
+    d = np.abs(outs[1] - outs[0])
+    print("direct vs stack: max", d.max(), "rel", rel(outs[1], outs[0]))
+    assert rel(outs[1], outs[0]) < 3e-4          # both round the same fp32 sums to fp16
+
+
 def test_forward_vid_matches_reference_golden(models, golden_dir):
     gs, _ = models
     g = np.load(os.path.join(golden_dir, "gestsync_clip.npz"))
@@ -79,6 +105,12 @@ def test_clip_features_match_reference_golden(models, golden_dir):
     frames, x = _golden_windows(g)
     feats_u8 = gs.extract_clip_feats(torch.from_numpy(frames).cuda())[0]
     assert rel(feats_u8, g["feats"]) < TOL
+    # fused u8 conv1 kernel vs the stack_frames + implicit-GEMM formulation: same fp16 operands,
+    # only the fp32 accumulation order differs
+    gs.engine.set_option("conv1_direct", 0)
+    feats_v0 = gs.extract_clip_feats(torch.from_numpy(frames).cuda())[0]
+    gs.engine.set_option("conv1_direct", 1)
+    assert rel(feats_u8, feats_v0) < 1e-3
     f01 = torch.from_numpy(frames.astype(np.float32) / np.float32(255.0)).cuda()
     feats_f32 = gs.extract_clip_feats(f01)[0]
     assert rel(feats_f32, g["feats"]) < TOL
