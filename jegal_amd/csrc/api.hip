@@ -659,6 +659,7 @@ int jg_set_chunk(jg_handle* h, int c) {
 int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!h || !name) return JG_ERR_ARG;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
     JG_FAIL(h, JG_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -185,6 +185,162 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant for the plain (Linear) GEMMs, K % 64 == 0:  tile 256(m) x 128(n) x 64(k), 8 waves
+// (4 x 2, each wave 64 x 64), both operand tiles brought in by global_load_lds_dwordx4 (no VGPR
+// round trip, no ds_write), two LDS stages (activations 32 KB + weights 16 KB (+16 KB lo) each).
+// The LDS image is lane-linear per wave-instruction (1 KB = 8 rows x 128 B), so the XOR swizzle is
+// applied to the per-lane SOURCE address and again on the fragment read (guide rule 21).
+// Rows beyond M / N are clamped to the last valid row (their results are never stored).
+// Workgroups that share an activation row panel (the N tiles of one M tile) are remapped onto one
+// XCD so the panel is fetched into that L2 once.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <bool W2>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_blocks) {
+    constexpr int BM = 256, BN = 128;
+    constexpr int XB = BM * 128, WB = BN * 128;
+    constexpr int STAGE = XB + WB * (W2 ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+
+    // XCD remap (bijective): blocks b, b+8, b+16, ... share an XCD -> give them consecutive tile ids
+    int bid = blockIdx.x;
+    {
+        const int q = total_blocks / 8, rr = total_blocks % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    }
+    const int n0 = (bid % n_tiles) * BN;
+    const int m0 = (bid / n_tiles) * BM;
+
+    // per-lane source pointers: wave-instruction i covers tile rows (wave*R + i)*8 .. +8, lane -> (row, phys chunk)
+    const int lrow = lane >> 3, pc = lane & 7;
+    const f16* xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int c = pc ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        xsrc[i] = a.A + (long)m * a.lda + c * 8;
+    }
+    const f16* whsrc[2];
+    const f16* wlsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + lrow;
+        const int c = pc ^ ((row >> 1) & 7);
+        int n = n0 + row;
+        n = n < a.N ? n : a.N - 1;
+        whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
+        wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xsrc[i] + k0), (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(whsrc[i] + k0), (lds_ptr_t)(base + XB + (wave * 2 + i) * 1024), 16, 0, 0);
+            if (W2)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wlsrc[i] + k0), (lds_ptr_t)(base + XB + WB + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / 64;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fsw = (frow >> 1) & 7;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* sX = smem + (kt & 1) * STAGE;
+        const char* sWh = sX + XB;
+        const char* sWl = sWh + WB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int choff = ((kk * 4 + fq) ^ fsw) << 4;
+            f16x8 wf[4], wl[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + frow;
+                wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
+                if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + frow;
+                xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 128 + choff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();     // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        if (n >= a.N) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+        if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + frow;
+            if (m >= a.M) continue;
+            f32x4 v = acc[i][j] * sc + bi;
+            if (a.res) {
+                const int rr = a.res_mod ? (m % a.res_mod) : m;
+                v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
+            }
+            if (a.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
+            if (a.out16) {
+                f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
+            }
+        }
+    }
+}
+
+template <bool W2>
+static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t lds = 2 * (size_t)(256 * 128 + 128 * 128 * (W2 ? 2 : 1));
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int mt = (a.M + 255) / 256, nt = (a.N + 127) / 128;
+    hipLaunchKernelGGL((gemm_glds_kernel<W2>), dim3((unsigned)(mt * nt)), dim3(512), lds, s, a, nt, mt * nt);
+    return hipGetLastError();
+}
+
 template <int WM, int WN, bool CONV, bool W2>
 static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -193,6 +349,9 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<WM, WN, CONV, W2>), dim3((unsigned)(mt * nt)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
+
+static bool g_use_glds = true;
+void gemm_set_glds(bool on) { g_use_glds = on; }
 
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
@@ -203,5 +362,7 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);
+    if (g_use_glds && a.K % 64 == 0 && a.M >= 256 && a.lda % 8 == 0 && a.ldw % 8 == 0)
+        return w2 ? launch_glds<true>(a, s) : launch_glds<false>(a, s);
     return w2 ? launch_variant<2, 2, false, true>(a, s) : launch_variant<2, 2, false, false>(a, s);
 }
