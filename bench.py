@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS)
-    ap.add_argument("--chunk", type=int, default=8)
+    ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--precision", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

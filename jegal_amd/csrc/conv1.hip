@@ -18,12 +18,10 @@
 //              (0..255 are exact in fp16; the 1/255 is applied in fp32 in the epilogue) and write the
 //              32-byte pixel slots into the other LDS buffer.  Their VALU/VMEM work overlaps the MFMA
 //              waves' matrix work on the same SIMDs.
-// Tile = 4 conv rows x 32 conv cols of one position: 16 input rows x 100 pixels x 32 B = 51,200 B,
-// double buffered (102,400 B LDS), one barrier per tile.  Persistent grid, one workgroup per CU,
+// Tile = 4 conv rows x 32 conv cols of one position: 16 input rows x 100 pixel slots (59,904 B with
+// the bank padding), double buffered (119,808 B LDS), one barrier per tile.  Persistent grid, one workgroup per CU,
 // tiles of one position are processed by neighbouring workgroups at the same time (its 5 frames =
 // 1.9 MB stay in the XCD L2s; a frame is re-read for 5 positions).
-// LDS swizzle: the two 16-B halves of pixel slot x are swapped when (x/24)&1 -- lanes r and r+8 of a
-// ds_read_b128 lane group read pixels 24 apart and would otherwise hit the same banks (2-way).
 #include "common.h"
 
 struct Conv1Args {
@@ -39,121 +37,161 @@ struct Conv1Args {
 namespace {
 constexpr int IH = 270, IW = 480, OH = 88, OW = 158;
 constexpr int TROWS = 16, TW = 100, SLOT = 32;
-constexpr int TILE_BYTES = TROWS * TW * SLOT;          // 51200
+// LDS image of a tile row: pixel slot x at byte 32*x + 16*(x/3) -- a 16-B pad after every 3 slots.
+// The MFMA patch reads walk pixels 3r+kw (lane r): 112*r + const, which puts the 16 lanes of every
+// ds_read_b128 group on 16 different 16-B bank quads (conflict-free, no swizzle, ONE base register
+// and compile-time immediates for all 49 (kh,kw) slots); the loaders' ds_write_b128 of 4-pixel groups
+// drop from 8-way (128-B stride) to 2-way conflicts.
+constexpr int ROW_PITCH = 3744;                        // >= 32*100 + 16*33, multiple of 16
+constexpr int TILE_BYTES = TROWS * ROW_PITCH;          // 59904
+__device__ __host__ constexpr int slot_off(int x) { return 32 * x + 16 * (x / 3); }
 constexpr int ROW_TILES = 22, COL_TILES = 5, TILES_PER_POS = ROW_TILES * COL_TILES;
 }
+
+struct C1Regs { uint32_t w[2][5][3]; };     // two (row, 4-pixel group) items x 5 frames x 12 bytes
 
 __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_mfma = wave < 4;
+    const long G = gridDim.x;
 
-    // ---- MFMA-wave state
-    const int chalf = wave & 1, mb0 = (wave >> 1) & 1;
-    const int r = lane & 31, h = lane >> 5;
-    f16x8 wreg[49];
-    int loff[7];
-    if (is_mfma) {
-#pragma unroll
-        for (int s = 0; s < 49; ++s)
-            wreg[s] = *reinterpret_cast<const f16x8*>(a.Wd + ((long)(s * 64 + chalf * 32 + r) * 16 + 8 * h));
-#pragma unroll
-        for (int kw = 0; kw < 7; ++kw) {
-            const int x = 3 * r + kw;
-            loff[kw] = x * SLOT + 16 * (h ^ ((x / 24) & 1));
-        }
-    }
-    const int ltid = tid - 256;
+    if (wave >= 4) {
+        // =========================== loader waves ===========================
+        // Software pipeline in registers: the global loads of tile t+2 are issued before tile t+1 is
+        // converted and written to LDS, so they have a whole tile time (and the barrier) to land.
+        const int ltid = tid - 256;
+        const int row0 = ltid / 25, g0 = ltid - row0 * 25;                 // item ltid        (< 256 <= 400)
+        const int it1 = ltid + 256;
+        const bool has1 = it1 < TROWS * 25;                                // item ltid + 256  (< 400)
+        const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
-    auto fill = [&](long tile, char* buf) {
-        const long nf = tile / TILES_PER_POS;
-        const int rem = (int)(tile - nf * TILES_PER_POS);
-        const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
-        const int b = (int)(nf / a.P), p = (int)(nf - (long)b * a.P);
-        const uint8_t* fb[5];
-#pragma unroll
-        for (int dt = 0; dt < 5; ++dt) {
-            int f = p + dt - a.pad;
-            f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
-            fb[dt] = a.src + ((long)b * a.T + f) * (IH * IW * 3);
-        }
-        for (int item = ltid; item < TROWS * 25; item += 256) {
-            const int row = item / 25, g = item - row * 25;
-            const int ih = rt * 12 + row;
-            const int px = j * 96 + 4 * g;
-            uint32_t w[5][3];
-            if (px < IW && ih < IH) {
-                const long off = ((long)ih * IW + px) * 3;
-#pragma unroll
-                for (int dt = 0; dt < 5; ++dt) {
-                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb[dt] + off);
-                    w[dt][0] = s[0]; w[dt][1] = s[1]; w[dt][2] = s[2];
-                }
-            } else {
-#pragma unroll
-                for (int dt = 0; dt < 5; ++dt) { w[dt][0] = 0; w[dt][1] = 0; w[dt][2] = 0; }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f16 e[16];
-#pragma unroll
-                for (int dt = 0; dt < 5; ++dt)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int bi = 3 * q + c;
-                        e[dt * 3 + c] = (f16)(float)((w[dt][bi >> 2] >> ((bi & 3) * 8)) & 0xffu);
-                    }
-                e[15] = (f16)0.f;
-                const int x = 4 * g + q;
-                const int f = (x / 24) & 1;
-                char* dst = buf + (row * TW + x) * SLOT;
-                *reinterpret_cast<uint4*>(dst + 16 * f) = *reinterpret_cast<uint4*>(&e[0]);
-                *reinterpret_cast<uint4*>(dst + 16 * (f ^ 1)) = *reinterpret_cast<uint4*>(&e[8]);
-            }
-        }
-    };
-
-    if (!is_mfma && (long)blockIdx.x < a.ntiles) fill(blockIdx.x, smem);
-
-    int it = 0;
-    for (long tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
-        __syncthreads();
-        char* cur = smem + (it & 1) * TILE_BYTES;
-        if (!is_mfma) {
-            const long nxt = tile + gridDim.x;
-            if (nxt < a.ntiles) fill(nxt, smem + ((it + 1) & 1) * TILE_BYTES);
-        } else {
+        auto issue = [&](long tile, C1Regs& R) {
             const long nf = tile / TILES_PER_POS;
             const int rem = (int)(tile - nf * TILES_PER_POS);
             const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+            const int b = (int)(nf / a.P), p = (int)(nf - (long)b * a.P);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int mb = mb0 + 2 * q;
-                const char* base = cur + 3 * mb * (TW * SLOT);
-                f32x16 acc;
+            for (int dt = 0; dt < 5; ++dt) {
+                int f = p + dt - a.pad;
+                f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
+                const uint8_t* fb = a.src + ((long)b * a.T + f) * (IH * IW * 3);
 #pragma unroll
-                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                for (int u = 0; u < 2; ++u) {
+                    const int row = u ? row1 : row0, g = u ? g1 : g0;
+                    const int ih = rt * 12 + row, px = j * 96 + 4 * g;
+                    const bool ok = (u == 0 || has1) && px < IW && ih < IH;
+                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb + ((long)ih * IW + px) * 3);
+                    R.w[u][dt][0] = ok ? s[0] : 0u;
+                    R.w[u][dt][1] = ok ? s[1] : 0u;
+                    R.w[u][dt][2] = ok ? s[2] : 0u;
+                }
+            }
+        };
+        auto cvt_write = [&](const C1Regs& R, char* buf) {
 #pragma unroll
-                for (int kh = 0; kh < 7; ++kh)
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !has1) break;
+                const int row = u ? row1 : row0, g = u ? g1 : g0;
 #pragma unroll
-                    for (int kw = 0; kw < 7; ++kw) {
-                        const f16x8 bfrag = *reinterpret_cast<const f16x8*>(base + kh * (TW * SLOT) + loff[kw]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[kh * 7 + kw], bfrag, acc, 0, 0, 0);
-                    }
-                // D[i][jj]: jj = lane&31 -> position, i = (x&3) + 8*(x>>2) + 4*h -> channel within the half
-                const int oh = rt * 4 + mb, ow = j * 32 + r;
-                if (ow < OW) {
-                    const int cb = chalf * 32 + 4 * h;
-                    f16* o = a.out + (((long)nf * OH + oh) * OW + ow) * 64 + cb;
+                for (int q = 0; q < 4; ++q) {
+                    f16 e[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                        if (a.scale) v *= *reinterpret_cast<const f32x4*>(a.scale + cb + 8 * g);
-                        v += *reinterpret_cast<const f32x4*>(a.shift + cb + 8 * g);
-                        f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
-                        *reinterpret_cast<f16x4*>(o + 8 * g) = hv;
-                    }
+                    for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int bi = 3 * q + c;
+                            e[dt * 3 + c] = (f16)(float)((R.w[u][dt][bi >> 2] >> ((bi & 3) * 8)) & 0xffu);
+                        }
+                    e[15] = (f16)0.f;
+                    const int x = 4 * g + q;
+                    char* dst = buf + row * ROW_PITCH + slot_off(x);
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&e[0]);
+                    *reinterpret_cast<uint4*>(dst + 16) = *reinterpret_cast<uint4*>(&e[8]);
+                }
+            }
+        };
+
+        C1Regs RA, RB;
+        long tile = blockIdx.x;
+        if (tile < a.ntiles) {
+            issue(tile, RA);
+            cvt_write(RA, smem);
+            if (tile + G < a.ntiles) issue(tile + G, RA);
+        }
+        // iteration `it` (tile): after the barrier the MFMA waves read buf[it&1]; we fill buf[(it+1)&1]
+        // with tile+G (already in registers) after issuing the loads of tile+2G into the other set.
+        int it = 0;
+        while (tile < a.ntiles) {
+            __syncthreads();
+            if (tile + G < a.ntiles) {
+                if (tile + 2 * G < a.ntiles) issue(tile + 2 * G, RB);
+                cvt_write(RA, smem + ((it + 1) & 1) * TILE_BYTES);
+            }
+            tile += G; ++it;
+            if (tile >= a.ntiles) break;
+            __syncthreads();
+            if (tile + G < a.ntiles) {
+                if (tile + 2 * G < a.ntiles) issue(tile + 2 * G, RA);
+                cvt_write(RB, smem + ((it + 1) & 1) * TILE_BYTES);
+            }
+            tile += G; ++it;
+        }
+        return;
+    }
+
+    // =========================== MFMA waves ===========================
+    const int chalf = wave & 1, mb0 = (wave >> 1) & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f16x8 wreg[49];
+#pragma unroll
+    for (int s = 0; s < 49; ++s)
+        wreg[s] = *reinterpret_cast<const f16x8*>(a.Wd + ((long)(s * 64 + chalf * 32 + r) * 16 + 8 * h));
+    // patch-fragment address of lane (r,h) for slot (kh,kw): pixel x = 3r+kw ->
+    //   (3*mb+kh)*ROW_PITCH + 32*x + 16*(x/3) + 16*h = [112*r + 16*h] + [kh*ROW_PITCH + 32*kw + 16*(kw/3)]
+    const int lbase = 112 * r + 16 * h;
+    const int cb = chalf * 32 + 4 * h;
+    constexpr int DEPTH = 4;                             // patch fragments in flight per wave
+    int it = 0;
+    for (long tile = blockIdx.x; tile < a.ntiles; tile += G, ++it) {
+        __syncthreads();
+        const char* cur = smem + (it & 1) * TILE_BYTES;
+        const long nf = tile / TILES_PER_POS;
+        const int rem = (int)(tile - nf * TILES_PER_POS);
+        const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int mb = mb0 + 2 * q;
+            const char* base = cur + 3 * mb * ROW_PITCH + lbase;
+            auto frag = [&](int s) -> f16x8 {
+                const int kh = s / 7, kw = s - kh * 7;
+                return *reinterpret_cast<const f16x8*>(base + kh * ROW_PITCH + 32 * kw + 16 * (kw / 3));
+            };
+            f32x16 acc;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+            f16x8 fr[DEPTH];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) fr[s] = frag(s);
+#pragma unroll
+            for (int s = 0; s < 49; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], fr[s % DEPTH], acc, 0, 0, 0);
+                if (s + DEPTH < 49) fr[s % DEPTH] = frag(s + DEPTH);
+                // pin the order: without this hipcc sinks every ds_read next to its MFMA (one fragment
+                // register, lgkmcnt(0) per MFMA) and the LDS latency is exposed 49 times per block
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // D[i][jj]: jj = lane&31 -> position, i = (x&3) + 8*(x>>2) + 4*h -> channel within the half
+            const int oh = rt * 4 + mb, ow = j * 32 + r;
+            if (ow < OW) {
+                f16* o = a.out + (((long)nf * OH + oh) * OW + ow) * 64 + cb;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    if (a.scale) v *= *reinterpret_cast<const f32x4*>(a.scale + cb + 8 * g);
+                    v += *reinterpret_cast<const f32x4*>(a.shift + cb + 8 * g);
+                    f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
+                    *reinterpret_cast<f16x4*>(o + 8 * g) = hv;
                 }
             }
         }
