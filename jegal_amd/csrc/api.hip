@@ -363,7 +363,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     if (direct) {
         // u8 HWC video: conv1 straight from the frames, the temporal stack lives only in LDS
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   h->c1_scale255, h->c1.bias, o1, h->stream); }));
+                                                                   1.0f / 255.0f, h->c1.bias, o1, h->stream); }));
     } else {
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
         RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
@@ -713,7 +713,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
     if (h->conv1_direct) {
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                   h->c1_scale255, h->c1.bias, o1, h->stream); }));
+                                                                   1.0f / 255.0f, h->c1.bias, o1, h->stream); }));
     } else {
         f16* S;
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));

@@ -23,15 +23,17 @@
 // tiles of one position are processed by neighbouring workgroups at the same time (its 5 frames =
 // 1.9 MB stay in the XCD L2s; a frame is re-read for 5 positions).
 #include "common.h"
+#include <cstdlib>
 
 struct Conv1Args {
     const uint8_t* src;   // [nclip][T][270][480][3]
     int nclip, T, pad, P;
     const f16* Wd;        // [49][64][16]  BN-folded weights, slot-major
-    const float* scale;   // [64] or nullptr (1/255 for u8 sources)
-    const float* shift;   // [64]
+    float scale;          // uniform epilogue scale (1/255 for u8 sources; BN scale is folded into Wd)
+    const float* shift;   // [64] BN-folded bias
     f16* out;             // [nclip*P][88][158][64]
     long ntiles;
+    int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no epilogue
 };
 
 namespace {
@@ -55,6 +57,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long G = gridDim.x;
+    // accumulator init table: shift[c] / scale, so that relu(acc * scale) = relu(conv * scale + shift)
+    // with no global load in the epilogue (an L2 round trip per block otherwise)
+    float* sInit = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    if (tid < 64) sInit[tid] = a.shift[tid] / a.scale;
+    __syncthreads();
 
     if (wave >= 4) {
         // =========================== loader waves ===========================
@@ -79,12 +86,16 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int row = u ? row1 : row0, g = u ? g1 : g0;
-                    const int ih = rt * 12 + row, px = j * 96 + 4 * g;
-                    const bool ok = (u == 0 || has1) && px < IW && ih < IH;
+                    // UNCONDITIONAL loads from a clamped address: a `cond ? load : 0` select makes hipcc branch
+                    // around every load and wait vmcnt(0) after it (10 serial L2 round trips per tile).
+                    // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never stored.
+                    int ih = rt * 12 + row, px = j * 96 + 4 * g;
+                    ih = ih < IH ? ih : IH - 1;
+                    px = px < IW ? px : IW - 4;
                     const uint32_t* s = reinterpret_cast<const uint32_t*>(fb + ((long)ih * IW + px) * 3);
-                    R.w[u][dt][0] = ok ? s[0] : 0u;
-                    R.w[u][dt][1] = ok ? s[1] : 0u;
-                    R.w[u][dt][2] = ok ? s[2] : 0u;
+                    R.w[u][dt][0] = s[0];
+                    R.w[u][dt][1] = s[1];
+                    R.w[u][dt][2] = s[2];
                 }
             }
         };
@@ -114,6 +125,10 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
 
         C1Regs RA, RB;
         long tile = blockIdx.x;
+        if (a.dbg & 1) {
+            for (; tile < a.ntiles; tile += G) __syncthreads();
+            return;
+        }
         if (tile < a.ntiles) {
             issue(tile, RA);
             cvt_write(RA, smem);
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     int it = 0;
     for (long tile = blockIdx.x; tile < a.ntiles; tile += G, ++it) {
         __syncthreads();
+        if (a.dbg & 2) continue;
         const char* cur = smem + (it & 1) * TILE_BYTES;
         const long nf = tile / TILES_PER_POS;
         const int rem = (int)(tile - nf * TILES_PER_POS);
@@ -169,7 +185,10 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             };
             f32x16 acc;
 #pragma unroll
-            for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 iv = *reinterpret_cast<const f32x4*>(sInit + cb + 8 * g);
+                acc[4 * g] = iv.x; acc[4 * g + 1] = iv.y; acc[4 * g + 2] = iv.z; acc[4 * g + 3] = iv.w;
+            }
             f16x8 fr[DEPTH];
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) fr[s] = frag(s);
@@ -183,13 +202,12 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             }
             // D[i][jj]: jj = lane&31 -> position, i = (x&3) + 8*(x>>2) + 4*h -> channel within the half
             const int oh = rt * 4 + mb, ow = j * 32 + r;
-            if (ow < OW) {
+            if (ow < OW && !(a.dbg & 4)) {
                 f16* o = a.out + (((long)nf * OH + oh) * OW + ow) * 64 + cb;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    if (a.scale) v *= *reinterpret_cast<const f32x4*>(a.scale + cb + 8 * g);
-                    v += *reinterpret_cast<const f32x4*>(a.shift + cb + 8 * g);
+                    v *= a.scale;
                     f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
                     *reinterpret_cast<f16x4*>(o + 8 * g) = hv;
                 }
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     }
 }
 
-hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, const float* scale,
+hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
                                const float* shift, f16* out, hipStream_t s) {
     static int num_cu = 0;
     static bool attr_set = false;
@@ -213,7 +231,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     }
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -221,8 +239,10 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
     a.Wd = Wd; a.scale = scale; a.shift = shift; a.out = out;
     a.ntiles = (long)nclip * a.P * TILES_PER_POS;
+    static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
+    a.dbg = dbg;
     if (a.ntiles <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(a.ntiles < num_cu ? a.ntiles : num_cu);
-    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), 2 * TILE_BYTES, s, a);
+    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), 2 * TILE_BYTES + 256, s, a);
     return hipGetLastError();
 }

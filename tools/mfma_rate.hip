@@ -1,0 +1,48 @@
+// Microbenchmark: issue rate of the f16 / bf16 MFMA shapes used by libjegal_hip (one wave per SIMD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    f16x8 a, b; bf16x8 ab, bb;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f - threadIdx.x * 0.002f); ab[i] = (__bf16)(float)a[i]; bb[i] = (__bf16)(float)b[i]; }
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    f32x4 d0 = {0}, d1 = {0}, d2 = {0}, d3 = {0};
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) { c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0); c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0); }
+        if (MODE == 1) { c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c1, 0, 0, 0); c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bb, c3, 0, 0, 0); }
+        if (MODE == 2) { d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d1, 0, 0, 0); d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d2, 0, 0, 0); d3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d3, 0, 0, 0); }
+        if (MODE == 3) { d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d0, 0, 0, 0); d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d1, 0, 0, 0); d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d2, 0, 0, 0); d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, d3, 0, 0, 0); }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    for (int i = 0; i < 4; ++i) s += d0[i] + d1[i] + d2[i] + d3[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE> void run(const char* name, double flop_per_mfma) {
+    float* out; hipMalloc(&out, 1024 * 256 * 4);
+    const int iters = 20000, blocks = 256;   // one 4-wave block per CU -> one wave per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 1000);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double mfmas = (double)blocks * 4 * iters * 4;
+    printf("%-22s %8.3f ms  %8.1f TFLOP/s   %.1f ns per MFMA per SIMD\n", name, ms, mfmas * flop_per_mfma / ms / 1e9, ms * 1e6 / (iters * 4.0));
+    hipFree(out);
+}
+int main() {
+    run<0>("32x32x16 f16", 32.0 * 32 * 16 * 2);
+    run<1>("32x32x16 bf16", 32.0 * 32 * 16 * 2);
+    run<2>("16x16x32 f16", 16.0 * 16 * 32 * 2);
+    run<3>("16x16x32 bf16", 16.0 * 16 * 32 * 2);
+    return 0;
+}
