@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <bool W2>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_blocks) {
+template <bool W2, bool CONV>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_blocks, const f16* zeros) {
     constexpr int BM = 256, BN = 128;
     constexpr int XB = BM * 128, WB = BN * 128;
     constexpr int STAGE = XB + WB * (W2 ? 2 : 1);
@@ -220,17 +220,34 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 
     // per-lane source pointers: wave-instruction i covers tile rows (wave*R + i)*8 .. +8, lane -> (row, phys chunk)
     const int lrow = lane >> 3, pc = lane & 7;
+    // CONV: the activation row m is an output pixel; per k-tile every lane turns its chunk's
+    // k = (kh,kw,c) into an NHWC address, or into `zeros` (a 128-B zero page) for padding taps and
+    // the K tail -- LDS-DMA cannot predicate, but it can read zeros.
     const f16* xsrc[4];
+    int xih[4], xiw[4];
+    int xchunk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + lrow;
         const int c = pc ^ ((row >> 1) & 7);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
-        xsrc[i] = a.A + (long)m * a.lda + c * 8;
+        xchunk[i] = c;
+        if (CONV) {
+            const int per = a.g.OH * a.g.OW;
+            const int img = m / per, rem = m - img * per;
+            const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+            xih[i] = oh * a.g.SH - a.g.PH;
+            xiw[i] = ow * a.g.SW - a.g.PW;
+            xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
+        } else {
+            xih[i] = xiw[i] = 0;
+            xsrc[i] = a.A + (long)m * a.lda + c * 8;
+        }
     }
     const f16* whsrc[2];
     const f16* wlsrc[2];
+    int wchunk[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + lrow;
@@ -239,19 +256,34 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         n = n < a.N ? n : a.N - 1;
         whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
         wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
+        wchunk[i] = c;
     }
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
         const int k0 = kt * 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xsrc[i] + k0), (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const f16* src;
+            if (CONV) {
+                const int k = k0 + xchunk[i] * 8;
+                const int ci = k & (a.g.C - 1);
+                const int kp = k >> a.g.cshift;
+                const int kh = kp / a.g.KW, kw = kp - kh * a.g.KW;
+                const int ih = xih[i] + kh, iw = xiw[i] + kw;
+                const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+                src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
+            } else {
+                src = xsrc[i] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(whsrc[i] + k0), (lds_ptr_t)(base + XB + (wave * 2 + i) * 1024), 16, 0, 0);
+            const bool kok = !CONV || (k0 + wchunk[i] * 8 < a.K);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + (wave * 2 + i) * 1024), 16, 0, 0);
             if (W2)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wlsrc[i] + k0), (lds_ptr_t)(base + XB + WB + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * 2 + i) * 1024), 16, 0, 0);
         }
     };
 
@@ -261,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.K / 64;
+    const int nk = (a.K + 63) / 64;
     const int frow = lane & 15, fq = lane >> 4;
     const int fsw = (frow >> 1) & 7;
 
@@ -326,18 +358,29 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     }
 }
 
-template <bool W2>
+static const f16* zero_page() {
+    static f16* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        hipMemset(z, 0, 256);
+    }
+    return z;
+}
+
+template <bool W2, bool CONV>
 static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds = 2 * (size_t)(256 * 128 + 128 * 128 * (W2 ? 2 : 1));
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const f16* z = zero_page();
+    if (!z) return hipErrorOutOfMemory;
     const int mt = (a.M + 255) / 256, nt = (a.N + 127) / 128;
-    hipLaunchKernelGGL((gemm_glds_kernel<W2>), dim3((unsigned)(mt * nt)), dim3(512), lds, s, a, nt, mt * nt);
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV>), dim3((unsigned)(mt * nt)), dim3(512), lds, s, a, nt, mt * nt, z);
     return hipGetLastError();
 }
 
@@ -359,10 +402,12 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     const bool narrow = a.N <= 64;
     if (conv) {
         if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
+        if (g_use_glds && a.M >= 256 && a.g.C % 8 == 0)
+            return w2 ? launch_glds<true, true>(a, s) : launch_glds<false, true>(a, s);
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);
     if (g_use_glds && a.K % 64 == 0 && a.M >= 256 && a.lda % 8 == 0 && a.ldw % 8 == 0)
-        return w2 ? launch_glds<true>(a, s) : launch_glds<false>(a, s);
+        return w2 ? launch_glds<true, false>(a, s) : launch_glds<false, false>(a, s);
     return w2 ? launch_variant<2, 2, false, true>(a, s) : launch_variant<2, 2, false, false>(a, s);
 }
