@@ -62,6 +62,7 @@ struct jg_handle {
     std::string err;
     int precision = JG_PREC_FP16_W2;
     int chunk = 8;
+    bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     std::map<std::string, HostTensor> host;
     std::vector<void*> wallocs;
@@ -413,7 +414,11 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
     if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
     if (B <= 0 || T <= 0) JG_FAIL(h, JG_ERR_ARG, "B and T must be positive");
     if (dtype != JG_U8 && dtype != JG_F32) JG_FAIL(h, JG_ERR_ARG, "frames dtype must be JG_U8 or JG_F32");
-    const int P = T + 20, S = 21;
+    // Edge padding 12 (inference_embs.py:283) gives T+20 conv positions, but positions 0..8 and
+    // T+11..T+19 each see five copies of one frame: evaluate the T+4 distinct ones (== padding 4) and
+    // let the window gather clamp.  Bit-identical to evaluating all T+20.
+    const int PAD = h->edge_dedup ? 4 : 12;
+    const int P = T + 2 * PAD - 4, S = 21;
     const size_t esz = dtype == JG_U8 ? 1 : 4;
     const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
     for (int b0 = 0; b0 < B; b0 += h->chunk) {
@@ -422,12 +427,12 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         float* conv;
         RET(wsalloc(h, (size_t)nb * P * 512, &conv));
         const char* src = reinterpret_cast<const char*>(frames) + (size_t)b0 * sb * esz;
-        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, 12, conv));
+        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
         const int nseq = nb * T, M = nseq * S;
         float* x32; f16 *x16, *hid, *mean16;
         RET(wsalloc(h, (size_t)M * 512, &x32));
         RET(wsalloc(h, (size_t)M * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, x32, x16, h->stream); }));
         RET(gs_transformer(h, x32, x16, nseq, S));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
@@ -458,7 +463,7 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
         float *x32, *full; f16 *x16, *hid;
         RET(wsalloc(h, (size_t)M * 512, &x32));
         RET(wsalloc(h, (size_t)M * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, 0, x32, x16, h->stream); }));
         RET(gs_transformer(h, x32, x16, nb, S));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)M * 1024, &full));
@@ -659,6 +664,7 @@ int jg_set_chunk(jg_handle* h, int c) {
 int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!h || !name) return JG_ERR_ARG;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
     JG_FAIL(h, JG_ERR_ARG, "unknown option '%s'", name);
 }

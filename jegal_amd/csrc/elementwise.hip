@@ -90,9 +90,11 @@ hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int
 
 // ---------------------------------------------------------------------------------------------
 // Window gather + positional encoding (gestsync.py:152, windowing of inference_embs.py:488-492):
-// x[(b,i,j)][:] = conv[b][i+j][:] + pe[j][:]   i < Twin, j < L.  conv is (B,P,D) fp32.
+// x[(b,i,j)][:] = conv[b][clamp(i+j-shift, 0, P-1)][:] + pe[j][:]   i < Twin, j < L.  conv is (B,P,D) fp32.
+// shift/clamp: with edge padding the first 9 and last 9 padded-clip positions see five copies of the
+// same frame, so the conv stack is only evaluated for the T+4 distinct positions (shift = 8).
 __global__ void window_gather_kernel(const float* __restrict__ conv, const float* __restrict__ pe, int B, int P, int Twin,
-                                     int L, int D, float* __restrict__ x32, f16* __restrict__ x16) {
+                                     int L, int D, int shift, float* __restrict__ x32, f16* __restrict__ x16) {
     const int dv = D / 4;
     const long total = (long)B * Twin * L * dv;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -102,7 +104,9 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
         r /= L;
         const int i = r % Twin;
         const int b = r / Twin;
-        f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + i + j) * D + d4 * 4);
+        int pp = i + j - shift;
+        pp = pp < 0 ? 0 : (pp > P - 1 ? P - 1 : pp);
+        f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + pp) * D + d4 * 4);
         v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
         *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
         f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
@@ -110,11 +114,11 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
     }
 }
 
-hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D,
+hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift,
                                 float* x32, f16* x16, hipStream_t s) {
     const long total = (long)B * Twin * L * (D / 4);
     const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, x32, x16);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, shift, x32, x16);
     return hipGetLastError();
 }
 

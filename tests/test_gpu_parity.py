@@ -111,6 +111,11 @@ def test_clip_features_match_reference_golden(models, golden_dir):
     feats_v0 = gs.extract_clip_feats(torch.from_numpy(frames).cuda())[0]
     gs.engine.set_option("conv1_direct", 1)
     assert rel(feats_u8, feats_v0) < 1e-3
+    # edge de-duplication (T+4 instead of T+20 conv positions) is bit-identical
+    gs.engine.set_option("edge_dedup", 0)
+    feats_all = gs.extract_clip_feats(torch.from_numpy(frames).cuda())[0]
+    gs.engine.set_option("edge_dedup", 1)
+    assert torch.equal(feats_all, feats_u8)
     f01 = torch.from_numpy(frames.astype(np.float32) / np.float32(255.0)).cuda()
     feats_f32 = gs.extract_clip_feats(f01)[0]
     assert rel(feats_f32, g["feats"]) < TOL
