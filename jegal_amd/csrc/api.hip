@@ -357,22 +357,25 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o4));
     RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o5));
     RET(wsalloc(h, (size_t)NF * 4 * 4 * 256, &p5));
-    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
     Epi e;
     e.relu = 1;
     const bool direct = src_u8 && sc == 1 && sw == 3 && sh == (long)FW * 3 && st == (long)FH * FW * 3 && sb == (long)T * st && h->conv1_direct;
     if (direct) {
-        // u8 HWC video: conv1 straight from the frames, the temporal stack lives only in LDS
+        // u8 HWC video: conv1 + max-pool straight from the frames; neither the temporal stack nor the
+        // pre-pool tensor exists in HBM
+        f16* edge;
+        RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, h->c1.bias, o1, h->stream); }));
+                                                                   1.0f / 255.0f, h->c1.bias, p1, edge, h->stream); }));
     } else {
+        RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
         RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
         e.scale = src_u8 ? h->c1_scale255 : nullptr;
         e.out16 = o1;
         RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+        RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
     }
-    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
@@ -715,20 +718,20 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     h->ws.reset();
     const int P = T + 2 * pad - 4;
     const long NF = (long)B * P;
-    f16* o1;
-    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
     if (h->conv1_direct) {
-        RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, h->c1.bias, o1, h->stream); }));
-    } else {
-        f16* S;
-        RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
-        const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
-        RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(frames_u8, 1, sb, st, sh, sw, 1, B, T, pad, FH, FW, S, h->stream); }));
-        const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);
-        Epi e; e.relu = 1; e.scale = h->c1_scale255; e.out16 = o1;
-        RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
+        f16* edge;
+        RET(wsalloc(h, conv1_edge_elems(NF), &edge));
+        return timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
+                                                                      1.0f / 255.0f, h->c1.bias, static_cast<f16*>(out_f16), edge, h->stream); });
     }
+    f16 *o1, *S;
+    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
+    RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
+    const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
+    RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(frames_u8, 1, sb, st, sh, sw, 1, B, T, pad, FH, FW, S, h->stream); }));
+    const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);
+    Epi e; e.relu = 1; e.scale = h->c1_scale255; e.out16 = o1;
+    RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
     return timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, static_cast<f16*>(out_f16), (int)NF, 88, 158, 64, h->stream); });
 }
 

@@ -1,27 +1,34 @@
-// conv1 of the GestSync VGG stack, direct from uint8 video frames (gfx950).
+// conv1 of the GestSync VGG stack, direct from uint8 video frames, with the max-pool fused (gfx950).
 //
-//   Conv3d(3->64, k(5,7,7), s(1,3,3)) + BatchNorm(eval) + ReLU          (gestsync.py:36-41, 308-316)
-//   evaluated ONCE per padded-clip position p (window de-duplication).
+//   Conv3d(3->64, k(5,7,7), s(1,3,3)) + BatchNorm(eval) + ReLU + MaxPool3d((1,3,3),(1,2,2))
+//   (gestsync.py:36-46, 308-321), evaluated ONCE per distinct padded-clip position
+//   (window de-duplication).  Neither the temporal stack nor the 88x158x64
+//   pre-pool tensor ever reaches HBM: in = raw u8 frames, out = pooled NHWC fp16 (43x78x64).
 //
 // Formulation: the 5 input frames of a position are treated as 15 channels ("temporal stack",
 // padded to a 16-element = 32-byte pixel slot), so K = 49 (kh,kw) slots x 16 = 784 and one
-// v_mfma_f32_32x32x16_f16 k-step is exactly one slot.  Nothing is materialised in HBM: the stack
-// exists only as an LDS tile built from the raw u8 frames.
+// v_mfma_f32_32x32x16_f16 k-step is exactly one slot.
 //
-// Workgroup = 8 waves on one CU (2 per SIMD):
+// Workgroup = 8 waves on one CU (2 per SIMD), persistent, one workgroup per CU:
 //   waves 0-3  MFMA waves.  Each keeps the complete K=784 weight panel of 32 output channels in
-//              196 VGPRs for the whole kernel (weights are the MFMA A operand, never re-read), and
-//              per tile computes two 32-position x 32-channel blocks: per k-step ONE ds_read_b128
-//              (the patch fragment, MFMA B operand) feeds one MFMA.
-//   waves 4-7  loader waves.  They read the 5 source frames of the next tile straight from the
-//              u8 HWC video (12-byte = 4-pixel groups, dword loads), convert u8 -> fp16 exactly
-//              (0..255 are exact in fp16; the 1/255 is applied in fp32 in the epilogue) and write the
-//              32-byte pixel slots into the other LDS buffer.  Their VALU/VMEM work overlaps the MFMA
-//              waves' matrix work on the same SIMDs.
-// Tile = 4 conv rows x 32 conv cols of one position: 16 input rows x 100 pixel slots (59,904 B with
-// the bank padding), double buffered (119,808 B LDS), one barrier per tile.  Persistent grid, one workgroup per CU,
-// tiles of one position are processed by neighbouring workgroups at the same time (its 5 frames =
-// 1.9 MB stay in the XCD L2s; a frame is re-read for 5 positions).
+//              196 VGPRs for the whole kernel (weights are the MFMA A operand, never re-read) and per
+//              tile computes two 32-position x 32-channel blocks; per k-step ONE ds_read_b128 (the
+//              patch fragment, MFMA B operand) feeds one MFMA, 4 fragments in flight (order pinned
+//              with sched_barrier).  Epilogue: scale, ReLU, fp16 -> LDS conv buffer (ds_write_b64).
+//   waves 4-7  loader/pool waves.  (a) read the 5 source frames of the tile after next straight
+//              from the u8 HWC video (dword loads, kept in registers across the barrier), (b) pool
+//              the previous tile's conv rows from the LDS conv buffer and store the pooled rows
+//              (16-B stores, full 128-B lines per pooled pixel), (c) convert the next tile's u8 -> fp16
+//              exactly (0..255 are exact; the 1/255 is applied in fp32 in the epilogue) and write its
+//              32-byte pixel slots.  Their VALU/VMEM/LDS work overlaps the matrix work on the same SIMDs.
+// Tile = 4 conv rows x 32 conv cols of one position (16 input rows x 100 pixel slots), double
+// buffered, one barrier per tile.  A workgroup marches DOWN a 32-column strip (22 tiles), so the
+// vertical 3x3/s2 pooling window that straddles two tiles is served by a one-row carry
+// (max of the previous tile's last two conv rows) kept in LDS.  The horizontal window that
+// straddles two strips (pooled column 16j+15 needs conv column 32(j+1)) is closed by a tiny
+// fix-up kernel from an "edge" side buffer (4 of 78 pooled columns).
+// Neighbouring workgroups work on the strips of one position at the same time, so its 5 frames
+// (1.9 MB) stay in the XCD L2s; a frame is re-read for 5 positions.
 #include "common.h"
 #include <cstdlib>
 
@@ -31,14 +38,16 @@ struct Conv1Args {
     const f16* Wd;        // [49][64][16]  BN-folded weights, slot-major
     float scale;          // uniform epilogue scale (1/255 for u8 sources; BN scale is folded into Wd)
     const float* shift;   // [64] BN-folded bias
-    f16* out;             // [nclip*P][88][158][64]
-    long ntiles;
-    int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no epilogue
+    f16* out;             // pooled [nclip*P][43][78][64]
+    f16* edge;            // [nclip*P][43][4][64]: vertically pooled conv column 32*j (j=1..4)
+    long nstrips;         // nclip * P * 5
+    int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle
 };
 
 namespace {
-constexpr int IH = 270, IW = 480, OH = 88, OW = 158;
-constexpr int TROWS = 16, TW = 100, SLOT = 32;
+constexpr int IH = 270, IW = 480;
+constexpr int PH = 43, PW = 78;
+constexpr int TROWS = 16;
 // LDS image of a tile row: pixel slot x at byte 32*x + 16*(x/3) -- a 16-B pad after every 3 slots.
 // The MFMA patch reads walk pixels 3r+kw (lane r): 112*r + const, which puts the 16 lanes of every
 // ds_read_b128 group on 16 different 16-B bank quads (conflict-free, no swizzle, ONE base register
@@ -47,10 +56,24 @@ constexpr int TROWS = 16, TW = 100, SLOT = 32;
 constexpr int ROW_PITCH = 3744;                        // >= 32*100 + 16*33, multiple of 16
 constexpr int TILE_BYTES = TROWS * ROW_PITCH;          // 59904
 __device__ __host__ constexpr int slot_off(int x) { return 32 * x + 16 * (x / 3); }
-constexpr int ROW_TILES = 22, COL_TILES = 5, TILES_PER_POS = ROW_TILES * COL_TILES;
+constexpr int ROW_TILES = 22, COL_TILES = 5;
+// conv buffer: [conv row 4][channel group 8][col 32][16 B]; carry: [channel group 8][col 32][16 B]
+constexpr int CONV_BYTES = 4 * 8 * 32 * 16;            // 16384
+constexpr int CARRY_BYTES = 8 * 32 * 16;               // 4096
+constexpr int OFF_CONV = 2 * TILE_BYTES;               // 119808
+constexpr int OFF_CARRY = OFF_CONV + 2 * CONV_BYTES;   // 152576
+constexpr int OFF_INIT = OFF_CARRY + 2 * CARRY_BYTES;  // 160768
+constexpr int LDS_BYTES = OFF_INIT + 256;              // 161024 <= 163840
 }
 
 struct C1Regs { uint32_t w[2][5][3]; };     // two (row, 4-pixel group) items x 5 frames x 12 bytes
+
+__device__ __forceinline__ f16x8 max8(f16x8 a, f16x8 b) {
+    f16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+    return r;
+}
 
 __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,24 +82,27 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const long G = gridDim.x;
     // accumulator init table: shift[c] / scale, so that relu(acc * scale) = relu(conv * scale + shift)
     // with no global load in the epilogue (an L2 round trip per block otherwise)
-    float* sInit = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    float* sInit = reinterpret_cast<float*>(smem + OFF_INIT);
     if (tid < 64) sInit[tid] = a.shift[tid] / a.scale;
     __syncthreads();
 
+    // local tile t of this workgroup -> strip blockIdx.x + (t/22)*G, row tile t%22
+    const long my_strips = a.nstrips > (long)blockIdx.x ? (a.nstrips - blockIdx.x + G - 1) / G : 0;
+    const long ntl = my_strips * ROW_TILES;
+
     if (wave >= 4) {
-        // =========================== loader waves ===========================
-        // Software pipeline in registers: the global loads of tile t+2 are issued before tile t+1 is
-        // converted and written to LDS, so they have a whole tile time (and the barrier) to land.
+        // =========================== loader / pool waves ===========================
         const int ltid = tid - 256;
         const int row0 = ltid / 25, g0 = ltid - row0 * 25;                 // item ltid        (< 256 <= 400)
         const int it1 = ltid + 256;
         const bool has1 = it1 < TROWS * 25;                                // item ltid + 256  (< 400)
         const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
-        auto issue = [&](long tile, C1Regs& R) {
-            const long nf = tile / TILES_PER_POS;
-            const int rem = (int)(tile - nf * TILES_PER_POS);
-            const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+        auto issue = [&](long t, C1Regs& R) {
+            const long strip = blockIdx.x + (t / ROW_TILES) * G;
+            const int rt = (int)(t % ROW_TILES);
+            const long nf = strip / COL_TILES;
+            const int j = (int)(strip - nf * COL_TILES);
             const int b = (int)(nf / a.P), p = (int)(nf - (long)b * a.P);
 #pragma unroll
             for (int dt = 0; dt < 5; ++dt) {
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                     const int row = u ? row1 : row0, g = u ? g1 : g0;
                     // UNCONDITIONAL loads from a clamped address: a `cond ? load : 0` select makes hipcc branch
                     // around every load and wait vmcnt(0) after it (10 serial L2 round trips per tile).
-                    // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never stored.
+                    // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never used.
                     int ih = rt * 12 + row, px = j * 96 + 4 * g;
                     ih = ih < IH ? ih : IH - 1;
                     px = px < IW ? px : IW - 4;
@@ -122,36 +148,69 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 }
             }
         };
+        // pooling of local tile t (its conv rows are in conv buffer t&1):
+        //   pooled row 2rt-1 = hpool(max(carry, R0)),  pooled row 2rt = hpool(max(R0,R1,R2)),  carry' = max(R2,R3)
+        const int pcg = (ltid >> 4) & 7, ppw = ltid & 15, prow = ltid >> 7;      // part A: 2 x 8 x 16 threads
+        const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
+        auto pool = [&](long t) {
+            const long strip = blockIdx.x + (t / ROW_TILES) * G;
+            const int rt = (int)(t % ROW_TILES);
+            const long nf = strip / COL_TILES;
+            const int j = (int)(strip - nf * COL_TILES);
+            const char* cbuf = smem + OFF_CONV + (int)(t & 1) * CONV_BYTES;
+            const char* cin = smem + OFF_CARRY + ((rt & 1) ^ 1) * CARRY_BYTES;
+            char* cout = smem + OFF_CARRY + (rt & 1) * CARRY_BYTES;
+            auto at = [&](const char* base, int row, int cg, int col) {
+                return *reinterpret_cast<const f16x8*>(base + ((row * 8 + cg) * 32 + col) * 16);
+            };
+            // vertical max of conv column `col` for this thread's pooled row
+            auto vmax = [&](int cg, int col) {
+                const f16x8 r0 = at(cbuf, 0, cg, col);
+                if (prow == 0) return max8(at(cin, 0, cg, col), r0);
+                return max8(max8(r0, at(cbuf, 1, cg, col)), at(cbuf, 2, cg, col));
+            };
+            const int ph = 2 * rt - 1 + prow;
+            const int pw = 16 * j + ppw;
+            if (ph >= 0 && pw < PW) {
+                const int c0 = 2 * ppw;
+                f16x8 m = max8(vmax(pcg, c0), vmax(pcg, c0 + 1));
+                if (ppw < 15) m = max8(m, vmax(pcg, c0 + 2));       // ppw == 15: column 32 belongs to strip j+1
+                *reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8) = m;
+            }
+            if (ppw == 0 && ph >= 0 && j > 0)                        // export column 0 for strip j-1's last pooled column
+                *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = vmax(pcg, 0);
+            // carry for the next tile of the strip
+            *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = max8(at(cbuf, 2, ccg, ccol), at(cbuf, 3, ccg, ccol));
+        };
 
-        C1Regs RA, RB;
-        long tile = blockIdx.x;
         if (a.dbg & 1) {
-            for (; tile < a.ntiles; tile += G) __syncthreads();
+            for (long t = 0; t <= ntl; ++t) __syncthreads();
             return;
         }
-        if (tile < a.ntiles) {
-            issue(tile, RA);
+        C1Regs RA, RB;
+        if (ntl > 0) {
+            issue(0, RA);
             cvt_write(RA, smem);
-            if (tile + G < a.ntiles) issue(tile + G, RA);
+            if (1 < ntl) issue(1, RA);
         }
-        // iteration `it` (tile): after the barrier the MFMA waves read buf[it&1]; we fill buf[(it+1)&1]
-        // with tile+G (already in registers) after issuing the loads of tile+2G into the other set.
-        int it = 0;
-        while (tile < a.ntiles) {
+        // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1;
+        // we issue the loads of tile t+2, pool tile t-1 and fill tile buffer (t+1)&1 with tile t+1.
+        long t = 0;
+        while (t < ntl) {
             __syncthreads();
-            if (tile + G < a.ntiles) {
-                if (tile + 2 * G < a.ntiles) issue(tile + 2 * G, RB);
-                cvt_write(RA, smem + ((it + 1) & 1) * TILE_BYTES);
-            }
-            tile += G; ++it;
-            if (tile >= a.ntiles) break;
+            if (t + 2 < ntl) issue(t + 2, RB);
+            if (t > 0) pool(t - 1);
+            if (t + 1 < ntl) cvt_write(RA, smem + (int)((t + 1) & 1) * TILE_BYTES);
+            ++t;
+            if (t >= ntl) break;
             __syncthreads();
-            if (tile + G < a.ntiles) {
-                if (tile + 2 * G < a.ntiles) issue(tile + 2 * G, RA);
-                cvt_write(RB, smem + ((it + 1) & 1) * TILE_BYTES);
-            }
-            tile += G; ++it;
+            if (t + 2 < ntl) issue(t + 2, RA);
+            pool(t - 1);
+            if (t + 1 < ntl) cvt_write(RB, smem + (int)((t + 1) & 1) * TILE_BYTES);
+            ++t;
         }
+        __syncthreads();                       // the MFMA waves have finished the last tile
+        if (ntl > 0) pool(ntl - 1);
         return;
     }
 
@@ -167,14 +226,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int lbase = 112 * r + 16 * h;
     const int cb = chalf * 32 + 4 * h;
     constexpr int DEPTH = 4;                             // patch fragments in flight per wave
-    int it = 0;
-    for (long tile = blockIdx.x; tile < a.ntiles; tile += G, ++it) {
+    for (long t = 0; t < ntl; ++t) {
         __syncthreads();
         if (a.dbg & 2) continue;
-        const char* cur = smem + (it & 1) * TILE_BYTES;
-        const long nf = tile / TILES_PER_POS;
-        const int rem = (int)(tile - nf * TILES_PER_POS);
-        const int rt = rem / COL_TILES, j = rem - rt * COL_TILES;
+        const char* cur = smem + (int)(t & 1) * TILE_BYTES;
+        char* cbuf = smem + OFF_CONV + (int)(t & 1) * CONV_BYTES;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int mb = mb0 + 2 * q;
@@ -200,24 +256,34 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 // register, lgkmcnt(0) per MFMA) and the LDS latency is exposed 49 times per block
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // D[i][jj]: jj = lane&31 -> position, i = (x&3) + 8*(x>>2) + 4*h -> channel within the half
-            const int oh = rt * 4 + mb, ow = j * 32 + r;
-            if (ow < OW && !(a.dbg & 4)) {
-                f16* o = a.out + (((long)nf * OH + oh) * OW + ow) * 64 + cb;
+            // D[i][jj]: jj = lane&31 -> conv column r, i = (x&3) + 8*(x>>2) + 4*h -> channel cb + 8g + (x&3).
+            // conv buffer [row mb][channel group chalf*4+g][col r][16 B], this lane's 4 channels = 8 B at +8h
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    v *= a.scale;
-                    f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
-                    *reinterpret_cast<f16x4*>(o + 8 * g) = hv;
-                }
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                v *= a.scale;
+                f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
+                *reinterpret_cast<f16x4*>(cbuf + ((mb * 8 + chalf * 4 + g) * 32 + r) * 16 + 8 * h) = hv;
             }
         }
     }
+    __syncthreads();                           // hand the last tile's conv rows to the pool waves
+}
+
+// out[nf][ph][16j+15][:] = max(out[...], edge[nf][ph][j][:])  for j = 0..3 (pooled columns 15,31,47,63)
+__global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restrict__ edge, long n) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;     // (nf*43+ph, j, cg)
+    if (idx >= n) return;
+    const int cg = idx & 7;
+    const int j = (idx >> 3) & 3;
+    const long rowi = idx >> 5;
+    f16* o = out + (rowi * PW + 16 * j + 15) * 64 + cg * 8;
+    const f16x8 e = *reinterpret_cast<const f16x8*>(edge + (rowi * 4 + j) * 64 + cg * 8);
+    *reinterpret_cast<f16x8*>(o) = max8(*reinterpret_cast<const f16x8*>(o), e);
 }
 
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               const float* shift, f16* out, hipStream_t s) {
+                               const float* shift, f16* out_pooled, f16* edge, hipStream_t s) {
     static int num_cu = 0;
     static bool attr_set = false;
     if (!num_cu) {
@@ -231,18 +297,24 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     }
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 256);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     Conv1Args a;
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
-    a.Wd = Wd; a.scale = scale; a.shift = shift; a.out = out;
-    a.ntiles = (long)nclip * a.P * TILES_PER_POS;
+    a.Wd = Wd; a.scale = scale; a.shift = shift; a.out = out_pooled; a.edge = edge;
+    a.nstrips = (long)nclip * a.P * COL_TILES;
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;
-    if (a.ntiles <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)(a.ntiles < num_cu ? a.ntiles : num_cu);
-    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), 2 * TILE_BYTES + 256, s, a);
+    if (a.nstrips <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)(a.nstrips < num_cu ? a.nstrips : num_cu);
+    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long n = (long)nclip * a.P * PH * 4 * 8;
+    hipLaunchKernelGGL(conv1_edge_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_pooled, edge, n);
     return hipGetLastError();
 }
+
+size_t conv1_edge_elems(long positions) { return (size_t)positions * PH * 4 * 64; }
