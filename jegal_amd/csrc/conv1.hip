@@ -69,10 +69,7 @@ constexpr int LDS_BYTES = OFF_INIT + 256;              // 161024 <= 163840
 struct C1Regs { uint32_t w[2][5][3]; };     // two (row, 4-pixel group) items x 5 frames x 12 bytes
 
 __device__ __forceinline__ f16x8 max8(f16x8 a, f16x8 b) {
-    f16x8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
-    return r;
+    return __builtin_elementwise_max(a, b);            // 4 x v_pk_max_f16
 }
 
 __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
@@ -150,7 +147,8 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         };
         // pooling of local tile t (its conv rows are in conv buffer t&1):
         //   pooled row 2rt-1 = hpool(max(carry, R0)),  pooled row 2rt = hpool(max(R0,R1,R2)),  carry' = max(R2,R3)
-        const int pcg = (ltid >> 4) & 7, ppw = ltid & 15, prow = ltid >> 7;      // part A: 2 x 8 x 16 threads
+        const int pcg = (ltid >> 4) & 7, ppw = ltid & 15;                         // part A: 2 x 8 x 16 threads
+        const int prow = __builtin_amdgcn_readfirstlane(ltid >> 7);               // wave-uniform: waves 4,5 / 6,7
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
         auto pool = [&](long t) {
             const long strip = blockIdx.x + (t / ROW_TILES) * G;
@@ -163,24 +161,33 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             auto at = [&](const char* base, int row, int cg, int col) {
                 return *reinterpret_cast<const f16x8*>(base + ((row * 8 + cg) * 32 + col) * 16);
             };
-            // vertical max of conv column `col` for this thread's pooled row
-            auto vmax = [&](int cg, int col) {
-                const f16x8 r0 = at(cbuf, 0, cg, col);
-                if (prow == 0) return max8(at(cin, 0, cg, col), r0);
-                return max8(max8(r0, at(cbuf, 1, cg, col)), at(cbuf, 2, cg, col));
-            };
+            // three conv columns of the pooling window; for ppw == 15 column 32 belongs to strip j+1
+            // (edge fix-up), so column 31 is simply read twice (max is idempotent) -- no divergent branch
+            const int c0 = 2 * ppw, c1 = c0 + 1, c2 = c0 + 2 < 32 ? c0 + 2 : 31;
+            const f16x8 q2 = at(cbuf, 2, ccg, ccol), q3 = at(cbuf, 3, ccg, ccol);
+            f16x8 m;
+            if (prow == 0) {            // pooled row 2rt-1: carry (conv rows 4rt-2, 4rt-1) and R0
+                const f16x8 a0 = at(cin, 0, pcg, c0), a1 = at(cin, 0, pcg, c1), a2 = at(cin, 0, pcg, c2);
+                const f16x8 b0 = at(cbuf, 0, pcg, c0), b1 = at(cbuf, 0, pcg, c1), b2 = at(cbuf, 0, pcg, c2);
+                m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(b1, b2));
+            } else {                    // pooled row 2rt: R0, R1, R2
+                const f16x8 a0 = at(cbuf, 0, pcg, c0), a1 = at(cbuf, 0, pcg, c1), a2 = at(cbuf, 0, pcg, c2);
+                const f16x8 b0 = at(cbuf, 1, pcg, c0), b1 = at(cbuf, 1, pcg, c1), b2 = at(cbuf, 1, pcg, c2);
+                const f16x8 d0 = at(cbuf, 2, pcg, c0), d1 = at(cbuf, 2, pcg, c1), d2 = at(cbuf, 2, pcg, c2);
+                m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(max8(b1, b2), max8(max8(d0, d1), d2)));
+            }
             const int ph = 2 * rt - 1 + prow;
             const int pw = 16 * j + ppw;
-            if (ph >= 0 && pw < PW) {
-                const int c0 = 2 * ppw;
-                f16x8 m = max8(vmax(pcg, c0), vmax(pcg, c0 + 1));
-                if (ppw < 15) m = max8(m, vmax(pcg, c0 + 2));       // ppw == 15: column 32 belongs to strip j+1
+            if (ph >= 0 && pw < PW)
                 *reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8) = m;
+            if (ph >= 0 && j > 0 && ppw == 0) {     // export conv column 0 (vertically pooled) for strip j-1's last pooled column
+                f16x8 e;
+                if (prow == 0) e = max8(at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
+                else e = max8(max8(at(cbuf, 0, pcg, 0), at(cbuf, 1, pcg, 0)), at(cbuf, 2, pcg, 0));
+                *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = e;
             }
-            if (ppw == 0 && ph >= 0 && j > 0)                        // export column 0 for strip j-1's last pooled column
-                *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = vmax(pcg, 0);
             // carry for the next tile of the strip
-            *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = max8(at(cbuf, 2, ccg, ccol), at(cbuf, 3, ccg, ccol));
+            *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = max8(q2, q3);
         };
 
         if (a.dbg & 1) {

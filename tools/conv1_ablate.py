@@ -15,4 +15,4 @@ eng.profile_reset(); eng.profile(True)
 for _ in range(3):
     eng.debug_conv1_pool(frames, 12)
 p = eng.profile_get()
-print("JG_CONV1_DBG=%s conv1 ms per 4 clips: %.3f  (pool %.3f)" % (os.environ.get("JG_CONV1_DBG", "0"), p["conv1"][0] / p["conv1"][1], p["maxpool"][0] / p["maxpool"][1]))
+print("JG_CONV1_DBG=%s conv1 ms per 4 clips: %.3f  (pool %.3f)" % (os.environ.get("JG_CONV1_DBG", "0"), p["conv1"][0] / p["conv1"][1], p["maxpool"][0] / max(1, p["maxpool"][1])))
