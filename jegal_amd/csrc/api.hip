@@ -249,6 +249,15 @@ int finalize_gestsync(jg_handle* h) {
         for (int s = 0; s < 49; ++s)
             for (int o = 0; o < 64; ++o)
                 for (int e = 0; e < 16; ++e) wd[((size_t)s * 64 + o) * 16 + e] = hostw[(size_t)o * 784 + s * 16 + e];
+        // bias lane: the kernel sets element 15 of every pixel slot to 1.0; shift*255 as hi+lo fp16 pair
+        std::vector<float> shift(64);
+        HIPCHK(h, hipMemcpy(shift.data(), h->c1.bias, 64 * sizeof(float), hipMemcpyDeviceToHost));
+        for (int o = 0; o < 64; ++o) {
+            const float v = shift[o] * 255.0f;
+            const f16 hi = (f16)v;
+            wd[((size_t)0 * 64 + o) * 16 + 15] = hi;
+            wd[((size_t)1 * 64 + o) * 16 + 15] = (f16)(v - (float)hi);
+        }
         RET(upload(h, wd, &h->c1_direct));
     }
     RET(make_linear(h, "ff_vid.0.weight", "ff_vid.0.bias", 512, 512, &h->ff0));
@@ -366,7 +375,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         f16* edge;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, h->c1.bias, p1, edge, h->stream); }));
+                                                                   1.0f / 255.0f, p1, edge, h->stream); }));
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -722,7 +731,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
         f16* edge;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         return timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                      1.0f / 255.0f, h->c1.bias, static_cast<f16*>(out_f16), edge, h->stream); });
+                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, h->stream); });
     }
     f16 *o1, *S;
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));

@@ -48,7 +48,7 @@ void gemm_set_glds(bool on);
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               const float* shift, f16* out_pooled, f16* edge, hipStream_t s);
+                               f16* out_pooled, f16* edge, hipStream_t s);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift,

@@ -37,7 +37,6 @@ struct Conv1Args {
     int nclip, T, pad, P;
     const f16* Wd;        // [49][64][16]  BN-folded weights, slot-major
     float scale;          // uniform epilogue scale (1/255 for u8 sources; BN scale is folded into Wd)
-    const float* shift;   // [64] BN-folded bias
     f16* out;             // pooled [nclip*P][43][78][64]
     f16* edge;            // [nclip*P][43][4][64]: vertically pooled conv column 32*j (j=1..4)
     long nstrips;         // nclip * P * 5
@@ -77,11 +76,9 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long G = gridDim.x;
-    // accumulator init table: shift[c] / scale, so that relu(acc * scale) = relu(conv * scale + shift)
-    // with no global load in the epilogue (an L2 round trip per block otherwise)
-    float* sInit = reinterpret_cast<float*>(smem + OFF_INIT);
-    if (tid < 64) sInit[tid] = a.shift[tid] / a.scale;
-    __syncthreads();
+    // The BN-folded bias rides in the GEMM: element 15 of every pixel slot is 1.0 and the weight panel
+    // holds shift/scale (hi+lo fp16 pair) at [slot 0][c][15] and [slot 1][c][15] -- no accumulator
+    // init read, no global load in the epilogue:  out = relu(acc * scale).
 
     // local tile t of this workgroup -> strip blockIdx.x + (t/22)*G, row tile t%22
     const long my_strips = a.nstrips > (long)blockIdx.x ? (a.nstrips - blockIdx.x + G - 1) / G : 0;
@@ -137,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                             const int bi = 3 * q + c;
                             e[dt * 3 + c] = (f16)(float)((R.w[u][dt][bi >> 2] >> ((bi & 3) * 8)) & 0xffu);
                         }
-                    e[15] = (f16)0.f;
+                    e[15] = (f16)1.f;        // bias lane: Wd[slot 0/1][c][15] carry shift/scale as a hi+lo fp16 pair
                     const int x = 4 * g + q;
                     char* dst = buf + row * ROW_PITCH + slot_off(x);
                     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&e[0]);
@@ -231,39 +228,39 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // patch-fragment address of lane (r,h) for slot (kh,kw): pixel x = 3r+kw ->
     //   (3*mb+kh)*ROW_PITCH + 32*x + 16*(x/3) + 16*h = [112*r + 16*h] + [kh*ROW_PITCH + 32*kw + 16*(kw/3)]
     const int lbase = 112 * r + 16 * h;
-    const int cb = chalf * 32 + 4 * h;
-    constexpr int DEPTH = 4;                             // patch fragments in flight per wave
+    constexpr int DEPTH = 6;                             // patch fragments in flight per wave
     for (long t = 0; t < ntl; ++t) {
         __syncthreads();
         if (a.dbg & 2) continue;
         const char* cur = smem + (int)(t & 1) * TILE_BYTES;
         char* cbuf = smem + OFF_CONV + (int)(t & 1) * CONV_BYTES;
+        // The two blocks of a tile form ONE stream of 98 (block, slot) steps with DEPTH fragments in
+        // flight, so block 1's first fragments are already loading while block 0's epilogue runs.
+        const char* base = cur + 3 * mb0 * ROW_PITCH + lbase;
+        auto frag = [&](int gi) -> f16x8 {
+            const int q = gi / 49, s = gi - q * 49;
+            const int kh = s / 7, kw = s - kh * 7;
+            return *reinterpret_cast<const f16x8*>(base + (6 * q + kh) * ROW_PITCH + 32 * kw + 16 * (kw / 3));
+        };
+        f16x8 fr[DEPTH];
+#pragma unroll
+        for (int gi = 0; gi < DEPTH; ++gi) fr[gi] = frag(gi);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int mb = mb0 + 2 * q;
-            const char* base = cur + 3 * mb * ROW_PITCH + lbase;
-            auto frag = [&](int s) -> f16x8 {
-                const int kh = s / 7, kw = s - kh * 7;
-                return *reinterpret_cast<const f16x8*>(base + kh * ROW_PITCH + 32 * kw + 16 * (kw / 3));
-            };
             f32x16 acc;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 iv = *reinterpret_cast<const f32x4*>(sInit + cb + 8 * g);
-                acc[4 * g] = iv.x; acc[4 * g + 1] = iv.y; acc[4 * g + 2] = iv.z; acc[4 * g + 3] = iv.w;
-            }
-            f16x8 fr[DEPTH];
-#pragma unroll
-            for (int s = 0; s < DEPTH; ++s) fr[s] = frag(s);
+            for (int x = 0; x < 16; ++x) acc[x] = 0.f;
 #pragma unroll
             for (int s = 0; s < 49; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], fr[s % DEPTH], acc, 0, 0, 0);
-                if (s + DEPTH < 49) fr[s % DEPTH] = frag(s + DEPTH);
+                const int gi = q * 49 + s;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s], fr[gi % DEPTH], acc, 0, 0, 0);
+                if (gi + DEPTH < 98) fr[gi % DEPTH] = frag(gi + DEPTH);
                 // pin the order: without this hipcc sinks every ds_read next to its MFMA (one fragment
                 // register, lgkmcnt(0) per MFMA) and the LDS latency is exposed 49 times per block
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // D[i][jj]: jj = lane&31 -> conv column r, i = (x&3) + 8*(x>>2) + 4*h -> channel cb + 8g + (x&3).
+            // D[i][jj]: jj = lane&31 -> conv column r, i = (x&3) + 8*(x>>2) + 4*h -> channel 32*chalf + 8g + 4h + (x&3).
             // conv buffer [row mb][channel group chalf*4+g][col r][16 B], this lane's 4 channels = 8 B at +8h
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -290,7 +287,7 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
 }
 
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               const float* shift, f16* out_pooled, f16* edge, hipStream_t s) {
+                               f16* out_pooled, f16* edge, hipStream_t s) {
     static int num_cu = 0;
     static bool attr_set = false;
     if (!num_cu) {
@@ -310,7 +307,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     }
     Conv1Args a;
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
-    a.Wd = Wd; a.scale = scale; a.shift = shift; a.out = out_pooled; a.edge = edge;
+    a.Wd = Wd; a.scale = scale; a.out = out_pooled; a.edge = edge;
     a.nstrips = (long)nclip * a.P * COL_TILES;
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;

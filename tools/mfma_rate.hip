@@ -39,7 +39,73 @@ template <int MODE> void run(const char* name, double flop_per_mfma) {
     printf("%-22s %8.3f ms  %8.1f TFLOP/s   %.1f ns per MFMA per SIMD\n", name, ms, mfmas * flop_per_mfma / ms / 1e9, ms * 1e6 / (iters * 4.0));
     hipFree(out);
 }
+template <int NACC>
+__global__ __launch_bounds__(256) void kchain(float* out, int iters, const _Float16* src) {
+    f16x8 a[8], b;
+    for (int j = 0; j < 8; ++j) a[j] = *(const f16x8*)(src + (threadIdx.x * 8 + j) * 8);
+    b = *(const f16x8*)(src + 4096 + threadIdx.x * 8);
+    f32x16 c0 = {0}, c1 = {0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (NACC == 1 || (j & 1) == 0) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b, c0, 0, 0, 0);
+            else c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], b, c1, 0, 0, 0);
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void kchain16(float* out, int iters, const _Float16* src) {
+    f16x8 a[8], b;
+    for (int j = 0; j < 8; ++j) a[j] = *(const f16x8*)(src + (threadIdx.x * 8 + j) * 8);
+    b = *(const f16x8*)(src + 4096 + threadIdx.x * 8);
+    f32x4 c[4] = {{0}, {0}, {0}, {0}};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b, c[j % NACC], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += c[0][i] + c[1][i] + c[2][i] + c[3][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC> void runchain16(const char* name) {
+    float* out; hipMalloc(&out, 1024 * 256 * 4);
+    _Float16* src; hipMalloc(&src, 65536 * 2);
+    static _Float16 hsrc[65536]; for (int i = 0; i < 65536; ++i) hsrc[i] = (_Float16)(((i * 2654435761u) >> 16 & 1023) / 512.0f - 1.0f);
+    hipMemcpy(src, hsrc, sizeof(hsrc), hipMemcpyHostToDevice);
+    const int iters = 10000, blocks = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kchain16<NACC>, dim3(blocks), dim3(256), 0, 0, out, 1000, src);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kchain16<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters, src);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s %8.3f ms  %.1f ns per MFMA per SIMD  (random data) -> %.0f TFLOP/s\n", name, ms, ms * 1e6 / (iters * 8.0), 1024.0 * 16 * 16 * 32 * 2 / (ms * 1e6 / (iters * 8.0)) / 1e3);
+}
+template <int NACC> void runchain(const char* name) {
+    float* out; hipMalloc(&out, 1024 * 256 * 4);
+    _Float16* src; hipMalloc(&src, 65536 * 2);
+    _Float16 hsrc[65536]; for (int i = 0; i < 65536; ++i) hsrc[i] = (_Float16)(((i * 2654435761u) >> 16 & 1023) / 512.0f - 1.0f);
+    hipMemcpy(src, hsrc, sizeof(hsrc), hipMemcpyHostToDevice);
+    const int iters = 10000, blocks = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kchain<NACC>, dim3(blocks), dim3(256), 0, 0, out, 1000, src);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kchain<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters, src);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s %8.3f ms  %.1f ns per MFMA per SIMD  (random data)\n", name, ms, ms * 1e6 / (iters * 8.0));
+}
 int main() {
+    runchain16<1>("16x16x32 f16 1 acc chain");
+    runchain16<2>("16x16x32 f16 2 acc chains");
+    runchain16<4>("16x16x32 f16 4 acc chains");
+    runchain<1>("32x32x16 f16 1 acc chain");
+    runchain<2>("32x32x16 f16 2 acc chains");
     run<0>("32x32x16 f16", 32.0 * 32 * 16 * 2);
     run<1>("32x32x16 bf16", 32.0 * 32 * 16 * 2);
     run<2>("16x16x32 f16", 16.0 * 16 * 32 * 2);
