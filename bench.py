@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--precision", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tuning experiments)")
     args = ap.parse_args()
 
     jdist.init_from_env("nccl")
@@ -83,6 +84,9 @@ def main():
     from jegal_amd.jegal import JEGAL
     eng = Engine(local, precision=args.precision)
     eng.set_chunk(args.chunk)
+    for o in args.opt:
+        k, v = o.split("=")
+        eng.set_option(k, int(v))
     GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
     JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
 

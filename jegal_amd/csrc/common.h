@@ -44,6 +44,8 @@ enum { LN_STD = 0, LN_ANNOTATED = 1 };
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
 void gemm_set_glds(bool on);
+void gemm_set_ring(bool on);
+void gemm_set_ring_cfg(int c);
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);

@@ -384,6 +384,203 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Ring variant: same 256x128 tile / 8 waves, but the K loop advances in HALF-stages of 32 k through a
+// 4-slot LDS ring (activations 16 KB + weights 8 KB (+8 KB lo) per slot).  The LDS-DMA of half-stage
+// h+3 is issued while half-stage h is computed, and the wait is a COUNTED s_waitcnt vmcnt (two
+// half-stages stay in flight across the raw s_barrier), so HBM/L2 latency is covered by ~3 compute
+// steps instead of 1 and nothing ever drains to vmcnt(0) inside the loop (guide T3/T4).
+// 64-byte LDS rows: chunk ^= 2*((row>>3)&1) keeps the 16x16x32 fragment reads conflict-free.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool W2, bool CONV, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs a, int n_tiles, int total_blocks, const f16* zeros) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int XI = (BM / 16) / NW, WI = (BN / 16) / NW;   // LDS-DMA instructions per wave per half-stage
+    constexpr int DIST = NS - 1;                              // half-stages issued ahead
+    constexpr int XB = BM * 64, WB = BN * 64;
+    constexpr int SLOTB = XB + WB * (W2 ? 2 : 1);
+    constexpr int PER = XI + WI * (W2 ? 2 : 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    int bid = blockIdx.x;
+    {
+        const int q = total_blocks / 8, rr = total_blocks % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    }
+    const int n0 = (bid % n_tiles) * BN;
+    const int m0 = (bid / n_tiles) * BM;
+
+    // wave-instruction i covers tile rows (wave*R + i)*16 .. +16; lane -> (row = l>>2, phys chunk = l&3)
+    const int lrow = lane >> 2, pc = lane & 3;
+    const f16* xsrc[XI];
+    int xih[XI], xiw[XI], xchunk[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * 16 + lrow;
+        const int c = pc ^ (((row >> 3) & 1) * 2);
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        xchunk[i] = c;
+        if (CONV) {
+            const int per = a.g.OH * a.g.OW;
+            const int img = m / per, rem = m - img * per;
+            const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+            xih[i] = oh * a.g.SH - a.g.PH;
+            xiw[i] = ow * a.g.SW - a.g.PW;
+            xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
+        } else {
+            xih[i] = xiw[i] = 0;
+            xsrc[i] = a.A + (long)m * a.lda + c * 8;
+        }
+    }
+    const f16* whsrc[WI];
+    const f16* wlsrc[WI];
+    int wchunk[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave * WI + i) * 16 + lrow;
+        const int c = pc ^ (((row >> 3) & 1) * 2);
+        int n = n0 + row;
+        n = n < a.N ? n : a.N - 1;
+        whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
+        wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
+        wchunk[i] = c;
+    }
+
+    auto stage = [&](int hs) {
+        char* base = smem + (hs % NS) * SLOTB;
+        const int k0 = hs * 32;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const f16* src;
+            if (CONV) {
+                const int k = k0 + xchunk[i] * 8;
+                const int ci = k & (a.g.C - 1);
+                const int kp = k >> a.g.cshift;
+                const int kh = kp / a.g.KW, kw = kp - kh * a.g.KW;
+                const int ih = xih[i] + kh, iw = xiw[i] + kw;
+                const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+                src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
+            } else {
+                src = xsrc[i] + k0;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const bool kok = !CONV || (k0 + wchunk[i] * 8 < a.K);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + (wave * WI + i) * 1024), 16, 0, 0);
+            if (W2)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * WI + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nh = (a.K + 31) / 32;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int choff = (fq ^ (((frow >> 3) & 1) * 2)) << 4;
+
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nh) stage(d);
+    for (int hs = 0; hs < nh; ++hs) {
+        // retire half-stage hs (this wave's own DMA), leave the younger ones in flight
+        const int later = nh - 1 - hs;
+        if (DIST >= 3 && later >= 2) wait_vmcnt<2 * PER>();
+        else if (DIST >= 2 && later >= 1) wait_vmcnt<PER>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // everyone's part of hs has landed; slot (hs+DIST)%NS == (hs-1)%NS is free
+        if (hs + DIST < nh) stage(hs + DIST);
+        const char* sX = smem + (hs % NS) * SLOTB;
+        const char* sWh = sX + XB;
+        const char* sWl = sWh + WB;
+        f16x8 wf[4], wl[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wn * 64 + i * 16 + frow;
+            wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 64 + choff);
+            if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 64 + choff);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wm * 64 + j * 16 + frow;
+            xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 64 + choff);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        if (n >= a.N) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+        if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + frow;
+            if (m >= a.M) continue;
+            f32x4 v = acc[i][j] * sc + bi;
+            if (a.res) {
+                const int rr = a.res_mod ? (m % a.res_mod) : m;
+                v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
+            }
+            if (a.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
+            if (a.out16) {
+                f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
+            }
+        }
+    }
+}
+
+template <bool W2, bool CONV, int WM, int WN, int NS>
+static hipError_t launch_ring_cfg(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr size_t lds = NS * (size_t)(BM * 64 + BN * 64 * (W2 ? 2 : 1));
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<W2, CONV, WM, WN, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const f16* z = zero_page();
+    if (!z) return hipErrorOutOfMemory;
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_ring_kernel<W2, CONV, WM, WN, NS>), dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), lds, s, a, nt, mt * nt, z);
+    return hipGetLastError();
+}
+
+static int g_ring_cfg = 1;     // 0: 256x128 tile, 8 waves, 4-slot ring (1 WG/CU); 1: 128x128, 4 waves, 2 slots (3 WG/CU); 2: 128x128, 3 slots
+void gemm_set_ring_cfg(int c) { g_ring_cfg = c; }
+
+template <bool W2, bool CONV>
+static hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
+    if (g_ring_cfg == 1) return launch_ring_cfg<W2, CONV, 2, 2, 2>(a, s);
+    if (g_ring_cfg == 2) return launch_ring_cfg<W2, CONV, 2, 2, 3>(a, s);
+    return launch_ring_cfg<W2, CONV, 4, 2, 4>(a, s);
+}
+
 template <int WM, int WN, bool CONV, bool W2>
 static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -394,7 +591,9 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
 }
 
 static bool g_use_glds = true;
+static bool g_use_ring = false;   // measured r1: the ring variants are 5-15 % slower than the 2-stage kernel
 void gemm_set_glds(bool on) { g_use_glds = on; }
+void gemm_set_ring(bool on) { g_use_ring = on; }
 
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
@@ -402,12 +601,16 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     const bool narrow = a.N <= 64;
     if (conv) {
         if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
-        if (g_use_glds && a.M >= 256 && a.g.C % 8 == 0)
+        if (g_use_glds && a.M >= 256 && a.g.C % 8 == 0) {
+            if (g_use_ring) return w2 ? launch_ring<true, true>(a, s) : launch_ring<false, true>(a, s);
             return w2 ? launch_glds<true, true>(a, s) : launch_glds<false, true>(a, s);
+        }
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);
-    if (g_use_glds && a.K % 64 == 0 && a.M >= 256 && a.lda % 8 == 0 && a.ldw % 8 == 0)
+    if (g_use_glds && a.K % 64 == 0 && a.M >= 256 && a.lda % 8 == 0 && a.ldw % 8 == 0) {
+        if (g_use_ring) return w2 ? launch_ring<true, false>(a, s) : launch_ring<false, false>(a, s);
         return w2 ? launch_glds<true, false>(a, s) : launch_glds<false, false>(a, s);
+    }
     return w2 ? launch_variant<2, 2, false, true>(a, s) : launch_variant<2, 2, false, false>(a, s);
 }
