@@ -80,8 +80,16 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // holds shift/scale (hi+lo fp16 pair) at [slot 0][c][15] and [slot 1][c][15] -- no accumulator
     // init read, no global load in the epilogue:  out = relu(acc * scale).
 
-    // local tile t of this workgroup -> strip blockIdx.x + (t/22)*G, row tile t%22
-    const long my_strips = a.nstrips > (long)blockIdx.x ? (a.nstrips - blockIdx.x + G - 1) / G : 0;
+    // Strip assignment, XCD-aware: workgroups b, b+8, b+16, ... share an XCD (and its 4 MB L2), so each
+    // XCD gets ONE contiguous range of strips (= whole clips) and its workgroups walk it together --
+    // the 5 frames of a position are then fetched into that L2 once instead of into all eight.
+    // local tile t of this workgroup -> strip s_lo + (t/22)*GX, row tile t%22
+    const long xcd = blockIdx.x & 7, xidx = blockIdx.x >> 3;
+    const long GX = (G + 7 - xcd) >> 3;                                 // workgroups on this XCD
+    const long per = (a.nstrips + 7) >> 3;
+    const long r_lo = xcd * per, r_hi = (r_lo + per < a.nstrips) ? r_lo + per : a.nstrips;
+    const long s_lo = r_lo + xidx;
+    const long my_strips = (s_lo < r_hi && GX > 0) ? (r_hi - s_lo + GX - 1) / GX : 0;
     const long ntl = my_strips * ROW_TILES;
 
     if (wave >= 4) {
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
         auto issue = [&](long t, C1Regs& R) {
-            const long strip = blockIdx.x + (t / ROW_TILES) * G;
+            const long strip = s_lo + (t / ROW_TILES) * GX;
             const int rt = (int)(t % ROW_TILES);
             const long nf = strip / COL_TILES;
             const int j = (int)(strip - nf * COL_TILES);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const int prow = __builtin_amdgcn_readfirstlane(ltid >> 7);               // wave-uniform: waves 4,5 / 6,7
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
         auto pool = [&](long t) {
-            const long strip = blockIdx.x + (t / ROW_TILES) * G;
+            const long strip = s_lo + (t / ROW_TILES) * GX;
             const int rt = (int)(t % ROW_TILES);
             const long nf = strip / COL_TILES;
             const int j = (int)(strip - nf * COL_TILES);
