@@ -17,6 +17,7 @@
 // * CONV: the activation "row" m is an output pixel (img,oh,ow) of an NHWC tensor and
 //   k = (kh,kw,c); out-of-image taps are zero-filled at staging time.
 #include "common.h"
+#include <cstdlib>
 
 template <int WM, int WN, bool CONV, bool W2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -198,8 +199,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <bool W2, bool CONV>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_blocks, const f16* zeros) {
+__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok) {
     constexpr int BM = 256, BN = 128;
     constexpr int XB = BM * 128, WB = BN * 128;
     constexpr int STAGE = XB + WB * (W2 ? 2 : 1);
@@ -208,57 +211,67 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-
-    // XCD remap (bijective): blocks b, b+8, b+16, ... share an XCD -> give them consecutive tile ids
-    int bid = blockIdx.x;
-    {
-        const int q = total_blocks / 8, rr = total_blocks % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    }
-    const int n0 = (bid % n_tiles) * BN;
-    const int m0 = (bid / n_tiles) * BM;
-
-    // per-lane source pointers: wave-instruction i covers tile rows (wave*R + i)*8 .. +8, lane -> (row, phys chunk)
+    const int G = gridDim.x;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fsw = (frow >> 1) & 7;
     const int lrow = lane >> 3, pc = lane & 7;
+
+    // Persistent: one workgroup per CU walks rounds of G tiles.  Within a round the workgroups of one
+    // XCD (b, b+8, ...) take consecutive tile ids, so the N tiles of an activation panel share an L2.
+    auto tile_of = [&](int round) -> int {
+        const int v0 = round * G;
+        if (v0 >= total_tiles) return -1;
+        const int cnt = total_tiles - v0 < G ? total_tiles - v0 : G;
+        const int b = blockIdx.x;
+        if (b >= cnt) return -1;
+        const int q = cnt / 8, rr = cnt % 8, xcd = b % 8, loc = b / 8;
+        return v0 + (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    };
+
+    // per-lane LDS-DMA source state of the current tile: wave-instruction i covers tile rows
+    // (wave*R + i)*8 .. +8, lane -> (row, physical 16-B chunk); the XOR swizzle is applied to the SOURCE.
     // CONV: the activation row m is an output pixel; per k-tile every lane turns its chunk's
-    // k = (kh,kw,c) into an NHWC address, or into `zeros` (a 128-B zero page) for padding taps and
-    // the K tail -- LDS-DMA cannot predicate, but it can read zeros.
+    // k = (kh,kw,c) into an NHWC address, or into `zeros` (a zero page) for padding taps and the K
+    // tail -- LDS-DMA cannot predicate, but it can read zeros.
     const f16* xsrc[4];
-    int xih[4], xiw[4];
-    int xchunk[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + lrow;
-        const int c = pc ^ ((row >> 1) & 7);
-        int m = m0 + row;
-        m = m < a.M ? m : a.M - 1;
-        xchunk[i] = c;
-        if (CONV) {
-            const int per = a.g.OH * a.g.OW;
-            const int img = m / per, rem = m - img * per;
-            const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
-            xih[i] = oh * a.g.SH - a.g.PH;
-            xiw[i] = ow * a.g.SW - a.g.PW;
-            xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
-        } else {
-            xih[i] = xiw[i] = 0;
-            xsrc[i] = a.A + (long)m * a.lda + c * 8;
-        }
-    }
+    int xih[4], xiw[4], xchunk[4];
     const f16* whsrc[2];
     const f16* wlsrc[2];
     int wchunk[2];
+    int n0 = 0, m0 = 0;
+    auto setup = [&](int bid) {
+        n0 = (bid % n_tiles) * BN;
+        m0 = (bid / n_tiles) * BM;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + lrow;
-        const int c = pc ^ ((row >> 1) & 7);
-        int n = n0 + row;
-        n = n < a.N ? n : a.N - 1;
-        whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
-        wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
-        wchunk[i] = c;
-    }
-
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + lrow;
+            const int c = pc ^ ((row >> 1) & 7);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            xchunk[i] = c;
+            if (CONV) {
+                const int per = a.g.OH * a.g.OW;
+                const int img = m / per, rem = m - img * per;
+                const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+                xih[i] = oh * a.g.SH - a.g.PH;
+                xiw[i] = ow * a.g.SW - a.g.PW;
+                xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
+            } else {
+                xih[i] = xiw[i] = 0;
+                xsrc[i] = a.A + (long)m * a.lda + c * 8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + lrow;
+            const int c = pc ^ ((row >> 1) & 7);
+            int n = n0 + row;
+            n = n < a.N ? n : a.N - 1;
+            whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
+            wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
+            wchunk[i] = c;
+        }
+    };
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
         const int k0 = kt * 64;
@@ -287,76 +300,161 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
     };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int nk = (a.K + 63) / 64;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int fsw = (frow >> 1) & 7;
+    const int nstores = (a.out32 ? 16 : 0) + (a.out16 ? 16 : 0);     // epilogue store instructions per wave (interior tile)
 
+    int round = 0;
+    int bid = tile_of(0);
+    if (bid < 0) return;
+    setup(bid);
     stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* sX = smem + (kt & 1) * STAGE;
-        const char* sWh = sX + XB;
-        const char* sWl = sWh + WB;
+    bool counted = false;      // the k-tile-0 DMA of this tile is older than exactly `nstores` epilogue stores
+    while (true) {
+        // The first k-tile of this tile was issued BEFORE the previous tile's epilogue stores, so it can be
+        // retired with a counted wait that leaves those stores in flight: the store burst (and its HBM
+        // latency) overlaps this tile's first MFMAs instead of idling the CU.
+        if (counted) {
+            if (nstores == 32) wait_vmcnt<32>(); else wait_vmcnt<16>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        const int cn0 = n0, cm0 = m0;
+        const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
+        const int nb = cn0 + wn * 64 + fq * 4;
+        const int mb = cm0 + wm * 64 + frow;
+
+        f32x4 acc[4][4], rs[4][4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int choff = ((kk * 4 + fq) ^ fsw) << 4;
-            f16x8 wf[4], wl[4], xf[4];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            if (kt == nk - 1 && interior && a.res) {
+                // residual prefetch: issued under the last k-tile's MFMAs, consumed in the epilogue
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = mb + j * 16;
+                    const int rr = a.res_mod ? (m % a.res_mod) : m;
+                    const float* rp = a.res + (long)rr * a.ldr + nb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rs[i][j] = *reinterpret_cast<const f32x4*>(rp + i * 16);
+                }
+            }
+            const char* sX = smem + (kt & 1) * STAGE;
+            const char* sWh = sX + XB;
+            const char* sWl = sWh + WB;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int choff = ((kk * 4 + fq) ^ fsw) << 4;
+                f16x8 wf[4], wl[4], xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wn * 64 + i * 16 + frow;
+                    wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
+                    if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 64 + j * 16 + frow;
+                    xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 128 + choff);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();     // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
+        }
+
+        // next tile: issue its first k-tile now, BEFORE the epilogue's stores
+        const int nbid = tile_of(++round);
+        if (nbid >= 0) {
+            setup(nbid);
+            stage(0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
+
+        // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile.
+        // Interior tiles take a branch-free path: ALL residual / scale / bias loads are issued first, then
+        // the math, then all stores.  (Per-element `if (m < M) load` made hipcc branch around every load
+        // and wait vmcnt(0) after each one: 16 serial HBM round trips per tile, 1/3 of the Linear time.)
+        if (interior) {
+            f32x4 sc[4], bi[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = wn * 64 + i * 16 + frow;
-                wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
-                if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
+                sc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                bi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (a.scale) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int row = wm * 64 + j * 16 + frow;
-                xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 128 + choff);
-            }
+                const long mo = (long)(mb + j * 16) * a.ldc + nb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = acc[i][j] * sc[i] + bi[i] + rs[i][j];
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = v;
+                    if (a.out16) {
+                        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                        *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = h;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = cn0 + wn * 64 + i * 16 + fq * 4;
+                if (n >= a.N) continue;
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+                    const int m = cm0 + wm * 64 + j * 16 + frow;
+                    if (m >= a.M) continue;
+                    f32x4 v = acc[i][j] * sc + bi;
+                    if (a.res) {
+                        const int rr = a.res_mod ? (m % a.res_mod) : m;
+                        v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
+                    }
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
+                    if (a.out16) {
+                        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                        *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
+                    }
                 }
-        }
-        __syncthreads();     // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
-    }
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fq * 4;
-        if (n >= a.N) continue;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-        if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + frow;
-            if (m >= a.M) continue;
-            f32x4 v = acc[i][j] * sc + bi;
-            if (a.res) {
-                const int rr = a.res_mod ? (m % a.res_mod) : m;
-                v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
-            }
-            if (a.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
-            if (a.out16) {
-                f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
             }
         }
+        if (nbid < 0) break;
+        counted = interior && counted_ok;
     }
 }
+
+static bool g_persistent = true;
+static int g_counted = 1;
+void gemm_set_persistent(bool on) { g_persistent = on; }
+void gemm_set_counted(int on) { g_counted = on; }
 
 static const f16* zero_page() {
     static f16* z = nullptr;
@@ -379,20 +477,19 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     }
     const f16* z = zero_page();
     if (!z) return hipErrorOutOfMemory;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     const int mt = (a.M + 255) / 256, nt = (a.N + 127) / 128;
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV>), dim3((unsigned)(mt * nt)), dim3(512), lds, s, a, nt, mt * nt, z);
+    const int tiles = mt * nt;
+    const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted);
     return hipGetLastError();
 }
-
-
-// ---------------------------------------------------------------------------------------------
-// Ring variant: same 256x128 tile / 8 waves, but the K loop advances in HALF-stages of 32 k through a
-// 4-slot LDS ring (activations 16 KB + weights 8 KB (+8 KB lo) per slot).  The LDS-DMA of half-stage
-// h+3 is issued while half-stage h is computed, and the wait is a COUNTED s_waitcnt vmcnt (two
-// half-stages stay in flight across the raw s_barrier), so HBM/L2 latency is covered by ~3 compute
-// steps instead of 1 and nothing ever drains to vmcnt(0) inside the loop (guide T3/T4).
-// 64-byte LDS rows: chunk ^= 2*((row>>3)&1) keeps the 16x16x32 fragment reads conflict-free.
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool W2, bool CONV, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs a, int n_tiles, int total_blocks, const f16* zeros) {
@@ -578,6 +675,7 @@ template <bool W2, bool CONV>
 static hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
     if (g_ring_cfg == 1) return launch_ring_cfg<W2, CONV, 2, 2, 2>(a, s);
     if (g_ring_cfg == 2) return launch_ring_cfg<W2, CONV, 2, 2, 3>(a, s);
+    if (g_ring_cfg == 3) return launch_ring_cfg<W2, CONV, 4, 2, 2>(a, s);     // 256x128, 64 KB (W2): 2 WG/CU
     return launch_ring_cfg<W2, CONV, 4, 2, 4>(a, s);
 }
 
