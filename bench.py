@@ -31,9 +31,12 @@ CLIPS, FRAMES = 32, 150
 CONV1_GFLOP_PER_CLIP = 154 * 13904 * 64 * 735 * 2 / 1e9
 TOTAL_GFLOP_PER_CLIP = 464.9       # SURVEY 8d total, v-only
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 (MI355X_MICROARCH.md)
+# HBM traffic of one conv1_direct_kernel launch (32 clips) from rocprofv3 PMC passes (profiles/r1b_pmc_hbm_traffic.csv
+# + profiles/README.md): FETCH_SIZE 1.39e6 KB (doubled: gfx950 counts 64 B per 128-B request), WRITE_SIZE 2.17e6 KB.
+CONV1_TRAFFIC_BYTES_PER_32CLIPS = (2 * 1.39e6 + 2.17e6) * 1024
 
 
-def cpu_baseline(clip_u8, n_windows=24):
+def cpu_baseline(clip_u8, n_windows=150):
     """The reference's algorithm (naive per-window conv stack, fp32, all host cores) via the oracle
     port, on a bounded sample: the first `n_windows` windows of one 150-frame clip plus the JEGAL
     gesture branch; extrapolated to a whole clip."""
@@ -47,9 +50,12 @@ def cpu_baseline(clip_u8, n_windows=24):
     padded = O.pad_clip(f01)
     vol = padded.permute(3, 0, 1, 2)
     with torch.no_grad():
-        xs = torch.stack([vol[:, i:i + 25] for i in range(n_windows)])
         t0 = time.perf_counter()
-        feats = O.gestsync_forward_vid(gsd, xs).mean(-1)
+        parts = []
+        for s0 in range(0, n_windows, 48):                       # the reference's batches of 48 windows
+            xs = torch.stack([vol[:, i:i + 25] for i in range(s0, min(n_windows, s0 + 48))])
+            parts.append(O.gestsync_forward_vid(gsd, xs).mean(-1))
+        feats = torch.cat(parts)
         t_win = time.perf_counter() - t0
         vis = feats[None].repeat(1, FRAMES // n_windows + 1, 1)[:, :FRAMES]
         t0 = time.perf_counter()
@@ -57,8 +63,8 @@ def cpu_baseline(clip_u8, n_windows=24):
         t_j = time.perf_counter() - t0
     per_clip = t_win * FRAMES / n_windows + t_j
     return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n_windows} of 150 windows of one clip through the naive per-window fp32 conv stack "
-                      f"({t_win:.1f} s) + JEGAL gesture branch ({t_j * 1e3:.0f} ms), extrapolated to a clip"}
+            "sample": f"{n_windows} of 150 windows of one seed-1234 clip through the reference algorithm (naive per-window "
+                      f"fp32 conv stack, batches of 48: {t_win:.1f} s) + JEGAL gesture branch ({t_j * 1e3:.0f} ms)"}
 
 
 def main():
@@ -136,7 +142,9 @@ def main():
                        "clips_per_gpu": args.clips, "frames": FRAMES, "precision_mode": args.precision, "chunk": args.chunk,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU, 154 distinct positions/clip)", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": CONV1_TRAFFIC_BYTES_PER_32CLIPS * clips_per_launch / 32.0,
+                         "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1b_pmc_hbm_traffic.csv (not re-measured in this run); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n,
                          "whole_path_frac": value / world * TOTAL_GFLOP_PER_CLIP / 1e3 / MFMA_PEAK_TFLOPS},
             "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},

@@ -622,6 +622,54 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs a, int
             }
     }
 
+    const bool interior = m0 + BM <= a.M && n0 + BN <= a.N;
+    if (interior) {
+        const int nb = n0 + wn * 64 + fq * 4;
+        const int mb = m0 + wm * 64 + frow;
+        f32x4 sc[4], bi[4], rs[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+            bi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.scale) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
+        }
+        if (a.res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = mb + j * 16;
+                const int rr = a.res_mod ? (m % a.res_mod) : m;
+                const float* rp = a.res + (long)rr * a.ldr + nb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rs[i][j] = *reinterpret_cast<const f32x4*>(rp + i * 16);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long mo = (long)(mb + j * 16) * a.ldc + nb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[i][j] * sc[i] + bi[i] + rs[i][j];
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = v;
+                if (a.out16) {
+                    f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                    *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = h;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + fq * 4;

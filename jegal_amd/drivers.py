@@ -1,0 +1,310 @@
+"""Command-line drivers mirroring the reference's hot-path scripts.
+
+    python -m jegal_amd.drivers extract_gestsync_feats ...   # preprocess/extract_gestsync_feats.py
+    python -m jegal_amd.drivers extract_jegal_embs ...       # evaluation/extract_jegal_embs.py
+    python -m jegal_amd.drivers evaluate_retrieval --path D  # evaluation/evaluate_retrieval.py
+    python -m jegal_amd.drivers evaluate_spotting  --path D  # evaluation/evaluate_spotting.py
+    python -m jegal_amd.drivers evaluate_asd --path D --file avs_asd.csv   # evaluation/evaluate_asd.py
+
+Same flags, file naming and on-disk formats as the reference.  What is upstream of the hot path is
+NOT rebuilt: video decoding / mediapipe masking (the drivers read already masked 270x480 crops as
+``<frames_dir>/<vid>/<track>.npy`` uint8 (T,270,480,3)), wav -> log-mel (``<video_dir>/<file>.mel.npy``
+(4T,80) fp32, librosa is third-party) and XLM-RoBERTa (``--text_states_dir`` with
+``<vid>__<track>.npz`` holding states/mask/ids/offsets, or a ``text_encoder`` passed from Python).
+Run under ``torchrun`` to shard over GPUs (contiguous blocks, extract_gestsync_feats.py:366-370).
+"""
+import argparse
+import ast
+import glob
+import math
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+from . import dist as jdist
+from . import synth
+
+
+def load_checkpoint(path, kind):
+    """inference_embs.py:92-119: torch.load(path)['state_dict'] with 'module.' stripped.
+    path == 'synthetic' gives the seeded synthetic weights (no checkpoints ship with the reference)."""
+    if path == "synthetic":
+        return synth.gestsync_state_dict() if kind == "gestsync" else synth.jegal_state_dict()
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+    return {k.replace("module.", ""): v for k, v in sd.items()}
+
+
+def _models(args, need_gestsync=False, need_jegal=False):
+    from ._lib import Engine
+    from .gestsync import GestSync
+    from .jegal import JEGAL
+    jdist.init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    eng = Engine.get()
+    gs = jg = None
+    if need_gestsync:
+        gs = GestSync(engine=eng).load_state_dict(load_checkpoint(args.checkpoint_path_gestsync, "gestsync"))
+    if need_jegal:
+        jg = JEGAL(engine=eng).load_state_dict(load_checkpoint(args.checkpoint_path, "jegal"))
+    return eng, gs, jg
+
+
+# --------------------------------------------------------------------------- extract_gestsync_feats
+def cmd_extract_gestsync_feats(argv):
+    p = argparse.ArgumentParser(prog="extract_gestsync_feats")
+    p.add_argument("--checkpoint_path_gestsync", required=True)
+    p.add_argument("--frames_dir", required=True, help="<vid>/<track>.npy masked uint8 crops (T,270,480,3)")
+    p.add_argument("--result_dir", required=True)
+    p.add_argument("--batch_size", type=int, default=48, help="accepted for compatibility; windows are never materialised")
+    p.add_argument("--clips_per_batch", type=int, default=8)
+    p.add_argument("--rank", type=int, default=None)
+    p.add_argument("--nshard", type=int, default=None)
+    args = p.parse_args(argv)
+    eng, gs, _ = _models(args, need_gestsync=True)
+    files = sorted(glob.glob(os.path.join(args.frames_dir, "*", "*.npy")))
+    lo, hi = jdist.shard_range(len(files), args.rank, args.nshard)
+    print("Total videos: {} | Start : End = {} : {}".format(len(files), lo, hi))
+    saved = err = 0
+    todo = []
+    for f in files[lo:hi]:
+        out = os.path.join(args.result_dir, f.split("/")[-2], os.path.basename(f))
+        if os.path.exists(out):                      # resume: skip-if-exists (extract_gestsync_feats.py:281-284)
+            saved += 1
+            continue
+        todo.append((f, out))
+    for f, out in todo:
+        try:
+            frames = np.load(f)
+            if frames.ndim != 4 or frames.shape[1:] != (270, 480, 3):
+                raise ValueError("expected (T,270,480,3), got %s" % (frames.shape,))
+            feats = gs.extract_clip_feats(torch.from_numpy(frames).to(eng.device))[0]
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            np.save(out, feats.cpu().numpy())
+            saved += 1
+        except Exception as e:                       # per-file try/except as the reference (:347-351)
+            err += 1
+            print("Error: ", e, " | Video file: ", f)
+    print("No of files saved = {} | Err = {}".format(saved, err))
+    return 0
+
+
+# --------------------------------------------------------------------------- extract_jegal_embs
+def _load_text_pack(path):
+    z = np.load(path, allow_pickle=True)
+    return z["states"], z["mask"], z["ids"], z["offsets"]
+
+
+def cmd_extract_jegal_embs(argv):
+    import pandas as pd
+    p = argparse.ArgumentParser(prog="extract_jegal_embs")
+    p.add_argument("--file_path", required=True)
+    p.add_argument("--checkpoint_path", required=True)
+    p.add_argument("--res_dir", required=True)
+    p.add_argument("--video_dir", required=True)
+    p.add_argument("--feature_dir", required=True)
+    p.add_argument("--text_states_dir", default=None)
+    p.add_argument("--modalities", default="vta", choices=["vta", "vt", "va", "ta", "v", "t", "a"])
+    p.add_argument("--batch_size", type=int, default=16)
+    args = p.parse_args(argv)
+    eng, _, jg = _models(args, need_jegal=True)
+    df = pd.read_csv(args.file_path)
+    print("Total files: {}".format(len(df)))
+    res_dir = os.path.join(args.res_dir, args.modalities)
+    os.makedirs(res_dir, exist_ok=True)
+    lo, hi = jdist.shard_range(len(df))
+    mod = args.modalities
+    saved = 0
+    rows = [df.iloc[i] for i in range(lo, hi)]
+    for s in range(0, len(rows), args.batch_size):
+        batch = []
+        for row in rows[s:s + args.batch_size]:
+            item = {"row": row, "file": row.filename}
+            if "v" in mod:
+                fn = os.path.join(args.feature_dir, row.filename + ".npy")
+                if not os.path.exists(fn):
+                    print("Visual feats file does not exist: ", fn)
+                    continue
+                item["feats"] = np.load(fn).astype(np.float32)
+                if item["feats"].ndim != 2 or item["feats"].shape[1] != 1024:
+                    continue
+            if "a" in mod:
+                fn = os.path.join(args.video_dir, row.filename + ".mel.npy")
+                if not os.path.exists(fn):
+                    print("Audio file does not exist: ", fn)
+                    continue
+                item["mel"] = np.load(fn).astype(np.float32)
+            if "t" in mod:
+                fn = os.path.join(args.text_states_dir or args.video_dir, row.filename.replace("/", "__") + ".npz")
+                if not os.path.exists(fn):
+                    print("Text states file does not exist: ", fn)
+                    continue
+                item["text"] = _load_text_pack(fn)
+            batch.append(item)
+        if not batch:
+            continue
+        n = len(batch)
+        vis = mask = audio = text = None
+        wbs = [ast.literal_eval(it["row"].word_boundaries) for it in batch] if mod != "v" else None
+        if "v" in mod:                                # pad_sequence + mask (dataset.py:336-340)
+            T = max(it["feats"].shape[0] for it in batch)
+            vis = torch.zeros((n, T, 1024))
+            mask = torch.zeros((n, T))
+            for i, it in enumerate(batch):
+                t = it["feats"].shape[0]
+                vis[i, :t] = torch.from_numpy(it["feats"])
+                mask[i, :t] = 1
+        if "a" in mod:
+            Tm = max(it["mel"].shape[0] for it in batch)
+            audio = torch.zeros((n, Tm, 80))
+            for i, it in enumerate(batch):
+                audio[i, :it["mel"].shape[0]] = torch.from_numpy(it["mel"])
+        if "t" in mod:
+            L = max(it["text"][0].shape[0] for it in batch)
+            st = np.zeros((n, L, 768), np.float32)
+            tm = np.zeros((n, L), np.int64)
+            ids = np.ones((n, L), np.int64)
+            offs = np.zeros((n, L, 2), np.int64)
+            for i, it in enumerate(batch):
+                l = it["text"][0].shape[0]
+                st[i, :l], tm[i, :l], ids[i, :l], offs[i, :l] = it["text"]
+            tbatch = [str(it["row"].phrase).split(" ") for it in batch]
+            text = (torch.from_numpy(st), torch.from_numpy(tm), tbatch, ids, offs)
+        am = None if audio is None else torch.ones((n, eng.audio_len(audio.shape[1])))
+        out = jg.forward_inference(visual_feats=vis, visual_mask=mask, text=text, audio=audio, audio_mask=am, word_boundaries=wbs)
+        gesture = content = None
+        if vis is not None and (text is not None or audio is not None):
+            gesture, content = out
+        elif vis is not None:
+            gesture = out
+        else:
+            content = out
+        for i, it in enumerate(batch):
+            g = c = None
+            if gesture is not None:                   # strip padded query rows
+                g = eng.l2norm(gesture[i, :it["feats"].shape[0]]).cpu().numpy()
+            if content is not None:                   # strip padded word rows
+                c = eng.l2norm(content[i, :len(wbs[i])]).cpu().numpy()
+            parts = it["file"].split("/")
+            with open(os.path.join(res_dir, parts[0] + "__" + parts[1] + ".pkl"), "wb") as f:
+                pickle.dump({"gesture_emb": g, "content_emb": c, "info": it["row"]}, f)
+            saved += 1
+    print("Saved {} files".format(saved))
+    print("Saved JEGAL features at: ", res_dir)
+    return 0
+
+
+# --------------------------------------------------------------------------- evaluators
+def _load_pkls(path):
+    files = sorted(glob.glob("{}/*.pkl".format(path)))
+    print("No of files = ", len(files))
+    feats = []
+    for fn in files:
+        with open(fn, "rb") as f:
+            feats.append(pickle.load(f))
+    return files, feats
+
+
+def cmd_evaluate_retrieval(argv):
+    from . import metrics as M
+    p = argparse.ArgumentParser(prog="evaluate_retrieval")
+    p.add_argument("--path", required=True)
+    args = p.parse_args(argv)
+    eng, _, _ = _models(args)
+    _, feats = _load_pkls(args.path)
+    lo, hi = jdist.shard_range(len(feats))
+    g = M.video_level(eng, [f["gesture_emb"] for f in feats[lo:hi]])
+    c = M.video_level(eng, [f["content_emb"] for f in feats[lo:hi]])
+    res = {}
+    for name, (a, b) in (("Content to Gesture", (c, g)), ("Gesture to Content", (g, c))):
+        m = M.retrieval_metrics(a, b, engine=eng)
+        res[name] = m
+        if jdist.rank() == 0:
+            print("{} Retrieval scores:".format(name))
+            print("R@1: {:.2f} - R@5: {:.2f} - R@10: {:.2f} - R@25: {:.2f} - R@50: {:.2f} | Median R: {:.1f}".format(
+                m["R1"] * 100, m["R5"] * 100, m["R10"] * 100, m["R25"] * 100, m["R50"] * 100, m["MR"]))
+    return res
+
+
+def cmd_evaluate_spotting(argv):
+    from . import metrics as M
+    p = argparse.ArgumentParser(prog="evaluate_spotting")
+    p.add_argument("--path", required=True)
+    p.add_argument("--threshold", type=float, default=0.5)
+    p.add_argument("--frame_threshold", type=int, default=9)
+    args = p.parse_args(argv)
+    eng, _, _ = _models(args)
+    _, feats = _load_pkls(args.path)
+    lo, hi = jdist.shard_range(len(feats))
+    feats = feats[lo:hi]
+    acc = M.spotting_accuracy([f["gesture_emb"] for f in feats], [f["content_emb"] for f in feats],
+                              [f["info"]["word_boundaries"] for f in feats],
+                              [f["info"]["target_word_boundary"] if not hasattr(f["info"], "target_word_boundary") else f["info"].target_word_boundary for f in feats],
+                              thresh=args.threshold, frame_thresh=args.frame_threshold, engine=eng)
+    if jdist.rank() == 0:
+        print("Word Spotting Accuracy: {}".format(acc))
+    return acc
+
+
+def cmd_evaluate_asd(argv):
+    import pandas as pd
+    from . import metrics as M
+    p = argparse.ArgumentParser(prog="evaluate_asd")
+    p.add_argument("--path", required=True)
+    p.add_argument("--file", required=True)
+    args = p.parse_args(argv)
+    eng, _, _ = _models(args)
+    df = pd.read_csv(args.file)
+    print("Total files: {}".format(len(df)))
+
+    def load(fname):
+        fn = os.path.join(args.path, fname.split("/")[0] + "__" + fname.split("/")[1] + ".pkl")
+        if not os.path.exists(fn):
+            return None
+        with open(fn, "rb") as f:
+            return pickle.load(f)
+
+    queries, cands = [], []
+    for i in range(len(df)):
+        row = df.iloc[i]
+        q = load(row.filename)
+        if q is None:
+            continue
+        cs = [np.asarray(q["gesture_emb"], np.float32).mean(axis=0)]
+        for neg in ast.literal_eval(row.neg_files):
+            d = load(neg)
+            if d is not None:
+                cs.append(np.asarray(d["gesture_emb"], np.float32).mean(axis=0))
+        queries.append(np.asarray(q["content_emb"], np.float32).mean(axis=0))
+        cands.append(np.stack(cs))
+    a2, a4, a6 = M.asd_accuracy(np.stack(queries), cands, engine=eng)
+    print("Total videos evaluated: {}".format(len(queries)))
+    for k, a in ((2, a2), (4, a4), (6, a6)):
+        print("{} spk: Acc: {:.3f}".format(k, a))
+    return a2, a4, a6
+
+
+COMMANDS = {
+    "extract_gestsync_feats": cmd_extract_gestsync_feats,
+    "extract_jegal_embs": cmd_extract_jegal_embs,
+    "evaluate_retrieval": cmd_evaluate_retrieval,
+    "evaluate_spotting": cmd_evaluate_spotting,
+    "evaluate_asd": cmd_evaluate_asd,
+}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if not argv or argv[0] not in COMMANDS:
+        print(__doc__)
+        return 2
+    res = COMMANDS[argv[0]](argv[1:])
+    return 0 if not isinstance(res, int) else res
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,83 @@
+"""End-to-end through the command-line drivers (the counterparts of extract_gestsync_feats.py,
+extract_jegal_embs.py and evaluate_*.py): crops -> .npy feats -> .pkl -> metrics, checked against the
+oracle on the same files."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import jegal_oracle as O
+from jegal_amd import drivers, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_drivers_roundtrip(tmp_path):
+    import pandas as pd
+    frames_dir, feat_dir, video_dir, res_dir = (str(tmp_path / d) for d in ("frames", "feats", "videos", "res"))
+    n, T, W = 5, 30, 4
+    rows = []
+    rng = np.random.default_rng(0)
+    for i in range(n):
+        vid, track = f"vid{i:02d}_1.0-2.0", "00000"
+        os.makedirs(os.path.join(frames_dir, vid), exist_ok=True)
+        os.makedirs(os.path.join(video_dir, vid), exist_ok=True)
+        Ti = T + 2 * i
+        np.save(os.path.join(frames_dir, vid, track + ".npy"), synth.synth_frames(100 + i, 1, Ti)[0])
+        np.save(os.path.join(video_dir, vid, track + ".mel.npy"), synth.synth_mel(200 + i, 1, 4 * Ti)[0])
+        st, mk, ids, offs = synth.synth_text(300 + i, 1, W)
+        np.savez(os.path.join(video_dir, f"{vid}__{track}.npz"), states=st[0], mask=mk[0], ids=ids[0], offsets=offs[0])
+        wb = [[f"w{j}", 6 * j, 6 * j + 4] for j in range(W)]
+        rows.append({"video_id": vid, "filename": f"{vid}/{track}", "phrase": " ".join(w[0] for w in wb),
+                     "word_boundaries": str(wb), "target_word_boundary": str(wb[i % W])})
+    csv = str(tmp_path / "avs.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+
+    assert drivers.main(["extract_gestsync_feats", "--checkpoint_path_gestsync", "synthetic", "--frames_dir", frames_dir,
+                         "--result_dir", feat_dir]) == 0
+    f0 = np.load(os.path.join(feat_dir, rows[0]["video_id"], "00000.npy"))
+    assert f0.shape == (T, 1024)
+    # resume: second run finds every output and recomputes nothing
+    mt = os.path.getmtime(os.path.join(feat_dir, rows[0]["video_id"], "00000.npy"))
+    drivers.main(["extract_gestsync_feats", "--checkpoint_path_gestsync", "synthetic", "--frames_dir", frames_dir, "--result_dir", feat_dir])
+    assert os.path.getmtime(os.path.join(feat_dir, rows[0]["video_id"], "00000.npy")) == mt
+
+    assert drivers.main(["extract_jegal_embs", "--file_path", csv, "--checkpoint_path", "synthetic", "--res_dir", res_dir,
+                         "--video_dir", video_dir, "--feature_dir", feat_dir, "--text_states_dir", video_dir,
+                         "--modalities", "vta", "--batch_size", "3"]) == 0
+    pk = os.path.join(res_dir, "vta")
+    files = sorted(os.listdir(pk))
+    assert files == sorted(r["video_id"] + "__00000.pkl" for r in rows)
+    feats = [pickle.load(open(os.path.join(pk, f), "rb")) for f in files]
+    for i, f in enumerate(feats):
+        assert f["gesture_emb"].shape == (T + 2 * i, 512) and f["content_emb"].shape == (W, 512)
+        assert np.allclose(np.linalg.norm(f["gesture_emb"], axis=1), 1, atol=1e-5)
+        assert f["info"]["phrase"] == rows[i]["phrase"]                 # pandas Series row, as the reference stores
+
+    # pkl contents vs the oracle for one clip (padded batch of 3 vs the clip alone on the CPU)
+    jsd = O.tensors(synth.jegal_state_dict())
+    i = 1
+    vis = torch.from_numpy(np.load(os.path.join(feat_dir, rows[i]["video_id"], "00000.npy")))[None]
+    mel = torch.from_numpy(np.load(os.path.join(video_dir, rows[i]["video_id"], "00000.mel.npy")))[None]
+    z = np.load(os.path.join(video_dir, rows[i]["video_id"] + "__00000.npz"))
+    pack = (z["states"][None], z["mask"][None], [rows[i]["phrase"].split(" ")], z["ids"][None], z["offsets"][None])
+    with torch.no_grad():
+        g, c = O.jegal_forward_inference(jsd, visual_feats=vis, visual_mask=torch.ones(1, vis.shape[1]), text=pack, audio=mel,
+                                         audio_mask=None, word_boundaries=[eval(rows[i]["word_boundaries"])])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel(feats[i]["gesture_emb"], O.l2_normalize(g[0]).numpy()) < 1e-3
+    assert rel(feats[i]["content_emb"], O.l2_normalize(c[0]).numpy()) < 1e-3
+
+    # evaluators on the written pkls == the reference's metric definitions on the same arrays
+    res = drivers.main(["evaluate_retrieval", "--path", pk])
+    res = drivers.cmd_evaluate_retrieval(["--path", pk])
+    gv = [f["gesture_emb"].mean(axis=0) for f in feats]
+    cv = [f["content_emb"].mean(axis=0) for f in feats]
+    assert res["Content to Gesture"] == O.compute_metrics(O.similarity_matrix(cv, gv).numpy())
+    assert res["Gesture to Content"] == O.compute_metrics(O.similarity_matrix(gv, cv).numpy())
+    acc = drivers.cmd_evaluate_spotting(["--path", pk])
+    wbs = [eval(r["word_boundaries"]) for r in rows]
+    tg = [wb.index(eval(r["target_word_boundary"])) for wb, r in zip(wbs, rows)]
+    assert acc == pytest.approx(O.spotting_accuracy([f["gesture_emb"] for f in feats], [f["content_emb"] for f in feats], wbs, tg))
