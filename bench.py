@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=1)
+    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tuning experiments)")
     args = ap.parse_args()

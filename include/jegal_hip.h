@@ -31,8 +31,11 @@ enum { JG_F32 = 0, JG_F16 = 1, JG_I64 = 2, JG_U8 = 3 };
 /* operand precision (DESIGN.md "precision"): fp32 accumulate / residual / LN / softmax in all modes */
 enum {
     JG_PREC_FP16 = 0,     /* every GEMM/conv operand fp16 */
-    JG_PREC_FP16_W2 = 1,  /* default: Linear weights carried as hi+lo fp16 pair (2 MFMAs) */
-    JG_PREC_FP16_W2_ALL = 2 /* conv weights split as well */
+    JG_PREC_FP16_W2 = 1,  /* Linear weights carried as hi+lo fp16 pair (2 MFMAs) */
+    JG_PREC_FP16_W2_ALL = 2, /* conv weights split as well */
+    JG_PREC_FP16_BC = 3   /* default: single fp16 weights on the gesture path, the systematic part of the weight
+                             rounding error (w - fp16(w)).E[x] folded into the bias by a calibration pass run inside
+                             jg_finalize_weights; content-path Linears keep the hi+lo split */
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -56,6 +59,10 @@ int jg_sync(jg_handle* h);
 int jg_load_tensor(jg_handle* h, const char* name, const void* data_host, const int64_t* shape_host, int ndim, int dtype);
 /* which: 1 = GestSync, 2 = JEGAL, 3 = both.  Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo. */
 int jg_finalize_weights(jg_handle* h, int which);
+
+/* Re-run the JG_PREC_FP16_BC calibration on caller-supplied clips (same layout as jg_gestsync_clip; device
+ * pointer) instead of the built-in synthetic ones, e.g. a few real videos.  frames == NULL: built-in clips. */
+int jg_calibrate_gesture(jg_handle* h, const void* frames, int frames_dtype, int B, int T);
 
 /* ---- GestSync (models/gestsync.py) ---------------------------------------------------------- */
 /* Per-clip features: frames (B,T,270,480,3) u8 (JG_U8, the /255 of inference_embs.py:282 is applied

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjegal_hip.so")
 
 JG_F32, JG_F16, JG_I64, JG_U8 = 0, 1, 2, 3
-PREC_FP16, PREC_FP16_W2, PREC_FP16_W2_ALL = 0, 1, 2
+PREC_FP16, PREC_FP16_W2, PREC_FP16_W2_ALL, PREC_FP16_BC = 0, 1, 2, 3
 STAGES = ["stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc"]
 
 _P = ctypes.c_void_p
@@ -29,6 +29,7 @@ _SIGS = {
     "jg_sync": [_P],
     "jg_load_tensor": [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I, _I],
     "jg_finalize_weights": [_P, _I],
+    "jg_calibrate_gesture": [_P, _P, _I, _I, _I],
     "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
     "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
@@ -170,6 +171,20 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.jg_sync(self.h))
+
+    def calibrate(self, frames=None):
+        """Re-run the bias-correction calibration (precision mode 3) on real clips (B,T,270,480,3);
+        None = the built-in deterministic synthetic clips used by finalize()."""
+        self._bind_stream()
+        if frames is None:
+            self._ck(self.lib.jg_calibrate_gesture(self.h, None, JG_U8, 0, 0))
+            return
+        frames = frames.to(self.device)
+        code = JG_U8 if frames.dtype == torch.uint8 else JG_F32
+        if code == JG_F32:
+            frames = frames.to(torch.float32)
+        frames = frames.contiguous()
+        self._ck(self.lib.jg_calibrate_gesture(self.h, _ptr(frames), code, frames.shape[0], frames.shape[1]))
 
     # ---- GestSync
     def gestsync_clip(self, frames):

@@ -41,6 +41,7 @@ struct GemmArgs {
 
 enum { LN_STD = 0, LN_ANNOTATED = 1 };
 
+
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
 void gemm_set_glds(bool on);
@@ -68,6 +69,7 @@ hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, h
 hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipStream_t s);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
                            int32_t* rank, int32_t* ties, hipStream_t s);

@@ -352,3 +352,28 @@ hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int
     hipLaunchKernelGGL(ragged_mean_kernel, dim3(n), dim3(256), 0, s, x, offsets, n, D, out);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Column sums of a row-major fp16 matrix (calibration pass of the bias-corrected precision mode):
+// out[k] += sum_m A[m][k].  8 columns per thread, rows strided over blockIdx.y, one float atomic per
+// (thread, column) at the end.  `out` is zeroed by the caller.
+__global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K, float* __restrict__ out) {
+    const int c8 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c8 * 8 >= K) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = blockIdx.y; m < M; m += gridDim.y) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(A + (long)m * lda + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + c8 * 8 + e, acc[e]);
+}
+
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipStream_t s) {
+    if (M <= 0 || K <= 0) return hipSuccess;
+    const int cols = K / 8;
+    const int gy = M < 64 ? M : 64;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, out);
+    return hipGetLastError();
+}
