@@ -201,16 +201,21 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool W2, bool CONV>
+// MI = 16-row MFMA tiles per wave along m (4: 64x64 wave tile, 8: 128x64); WM x WN waves.
+//   <4,4,2>: 256x128 block tile (hi+lo weights fit two LDS stages);  <8,2,4>: 256x256 block tile for single-fp16
+//   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
+template <bool W2, bool CONV, int MI, int WM, int WN>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok) {
-    constexpr int BM = 256, BN = 128;
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int BM = 16 * MI * WM, BN = 64 * WN;
+    constexpr int XI = BM / 64, WI = BN / 64;            // LDS-DMA instructions (8 rows each) per wave per k-tile
     constexpr int XB = BM * 128, WB = BN * 128;
     constexpr int STAGE = XB + WB * (W2 ? 2 : 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WM, wn = wave / WM;
     const int G = gridDim.x;
     const int frow = lane & 15, fq = lane >> 4;
     const int fsw = (frow >> 1) & 7;
@@ -233,18 +238,18 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     // CONV: the activation row m is an output pixel; per k-tile every lane turns its chunk's
     // k = (kh,kw,c) into an NHWC address, or into `zeros` (a zero page) for padding taps and the K
     // tail -- LDS-DMA cannot predicate, but it can read zeros.
-    const f16* xsrc[4];
-    int xih[4], xiw[4], xchunk[4];
-    const f16* whsrc[2];
-    const f16* wlsrc[2];
-    int wchunk[2];
+    const f16* xsrc[XI];
+    int xih[XI], xiw[XI], xchunk[XI];
+    const f16* whsrc[WI];
+    const f16* wlsrc[WI];
+    int wchunk[WI];
     int n0 = 0, m0 = 0;
     auto setup = [&](int bid) {
         n0 = (bid % n_tiles) * BN;
         m0 = (bid / n_tiles) * BM;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wave * 4 + i) * 8 + lrow;
+        for (int i = 0; i < XI; ++i) {
+            const int row = (wave * XI + i) * 8 + lrow;
             const int c = pc ^ ((row >> 1) & 7);
             int m = m0 + row;
             m = m < a.M ? m : a.M - 1;
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 8 + lrow;
+        for (int i = 0; i < WI; ++i) {
+            const int row = (wave * WI + i) * 8 + lrow;
             const int c = pc ^ ((row >> 1) & 7);
             int n = n0 + row;
             n = n < a.N ? n : a.N - 1;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         char* base = smem + buf * STAGE;
         const int k0 = kt * 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XI; ++i) {
             const f16* src;
             if (CONV) {
                 const int k = k0 + xchunk[i] * 8;
@@ -289,19 +294,19 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             } else {
                 src = xsrc[i] + k0;
             }
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WI; ++i) {
             const bool kok = !CONV || (k0 + wchunk[i] * 8 < a.K);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + (wave * WI + i) * 1024), 16, 0, 0);
             if (W2)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * WI + i) * 1024), 16, 0, 0);
         }
     };
 
     const int nk = (a.K + 63) / 64;
-    const int nstores = (a.out32 ? 16 : 0) + (a.out16 ? 16 : 0);     // epilogue store instructions per wave (interior tile)
+    const int nstores = (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);     // epilogue store instructions per wave (interior tile)
 
     int round = 0;
     int bid = tile_of(0);
@@ -313,8 +318,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         // The first k-tile of this tile was issued BEFORE the previous tile's epilogue stores, so it can be
         // retired with a counted wait that leaves those stores in flight: the store burst (and its HBM
         // latency) overlaps this tile's first MFMAs instead of idling the CU.
-        if (counted) {
-            if (nstores == 32) wait_vmcnt<32>(); else wait_vmcnt<16>();
+        if (counted && nstores == 16) {
+            wait_vmcnt<16>();
+        } else if (counted && nstores == 32) {
+            wait_vmcnt<32>();
         } else {
             wait_vmcnt<0>();
         }
@@ -322,23 +329,24 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         const int cn0 = n0, cm0 = m0;
         const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
-        const int mb = cm0 + wm * 64 + frow;
+        const int mb = cm0 + wm * (16 * MI) + frow;
+        constexpr bool PREFETCH_RES = MI <= 4;        // 128x64 wave tiles have no registers to spare for it
 
-        f32x4 acc[4][4], rs[4][4];
+        f32x4 acc[4][MI], rs[4][PREFETCH_RES ? MI : 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < MI; ++j) {
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (PREFETCH_RES) rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-            if (kt == nk - 1 && interior && a.res) {
+            if (PREFETCH_RES && kt == nk - 1 && interior && a.res) {
                 // residual prefetch: issued under the last k-tile's MFMAs, consumed in the epilogue
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < (PREFETCH_RES ? MI : 1); ++j) {
                     const int m = mb + j * 16;
                     const int rr = a.res_mod ? (m % a.res_mod) : m;
                     const float* rp = a.res + (long)rr * a.ldr + nb;
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int choff = ((kk * 4 + fq) ^ fsw) << 4;
-                f16x8 wf[4], wl[4], xf[4];
+                f16x8 wf[4], wl[4], xf[MI];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = wn * 64 + i * 16 + frow;
@@ -360,14 +368,14 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                     if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = wm * 64 + j * 16 + frow;
+                for (int j = 0; j < MI; ++j) {
+                    const int row = wm * (16 * MI) + j * 16 + frow;
                     xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 128 + choff);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < MI; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                         if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
                     }
@@ -403,11 +411,23 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < MI; ++j) {
                 const long mo = (long)(mb + j * 16) * a.ldc + nb;
+                f32x4 rj[4];
+                if (!PREFETCH_RES) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.res) {
+                        const int m = mb + j * 16;
+                        const int rr = a.res_mod ? (m % a.res_mod) : m;
+                        const float* rp = a.res + (long)rr * a.ldr + nb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rj[i] = *reinterpret_cast<const f32x4*>(rp + i * 16);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f32x4 v = acc[i][j] * sc[i] + bi[i] + rs[i][j];
+                    f32x4 v = acc[i][j] * sc[i] + bi[i] + (PREFETCH_RES ? rs[i][j] : rj[i]);
                     if (a.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
@@ -427,8 +447,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
                 if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = cm0 + wm * 64 + j * 16 + frow;
+                for (int j = 0; j < MI; ++j) {
+                    const int m = cm0 + wm * (16 * MI) + j * 16 + frow;
                     if (m >= a.M) continue;
                     f32x4 v = acc[i][j] * sc + bi;
                     if (a.res) {
@@ -465,12 +485,13 @@ static const f16* zero_page() {
     return z;
 }
 
-template <bool W2, bool CONV>
-static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
+template <bool W2, bool CONV, int MI, int WM, int WN>
+static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t lds = 2 * (size_t)(256 * 128 + 128 * 128 * (W2 ? 2 : 1));
+    constexpr int BM = 16 * MI * WM, BN = 64 * WN;
+    constexpr size_t lds = 2 * (size_t)(BM * 128 + BN * 128 * (W2 ? 2 : 1));
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV, MI, WM, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -484,11 +505,22 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
         num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int mt = (a.M + 255) / 256, nt = (a.N + 127) / 128;
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const int tiles = mt * nt;
     const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted);
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted);
     return hipGetLastError();
+}
+
+static bool g_big_tile = true;
+void gemm_set_big_tile(bool on) { g_big_tile = on; }
+
+template <bool W2, bool CONV>
+static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
+    if constexpr (!W2) {
+        if (g_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
+    }
+    return launch_glds_cfg<W2, CONV, 4, 4, 2>(a, s);
 }
 
 template <bool W2, bool CONV, int WM, int WN, int NS>
