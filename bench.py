@@ -30,6 +30,7 @@ CLIPS, FRAMES = 32, 150
 # really evaluates: 154 x 13904 px x 64 ch x 735 taps x 2 = 201.5 GFLOP/clip (never on padded K/tiles).
 CONV1_GFLOP_PER_CLIP = 154 * 13904 * 64 * 735 * 2 / 1e9
 TOTAL_GFLOP_PER_CLIP = 464.9       # SURVEY 8d total, v-only
+LINEAR_GFLOP_PER_CLIP = 131.1      # GestSync transformer + ff_vid (124.7) + JEGAL gesture + align (6.4)
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 (MI355X_MICROARCH.md)
 # HBM traffic of one conv1_direct_kernel launch (32 clips) from rocprofv3 PMC passes (profiles/r1b_pmc_hbm_traffic.csv
 # + profiles/README.md): FETCH_SIZE 1.39e6 KB (doubled: gfx950 counts 64 B per 128-B request), WRITE_SIZE 2.17e6 KB.
@@ -147,6 +148,12 @@ def main():
                          "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1b_pmc_hbm_traffic.csv (not re-measured in this run); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n,
                          "whole_path_frac": value / world * TOTAL_GFLOP_PER_CLIP / 1e3 / MFMA_PEAK_TFLOPS},
+            # second-largest consumer: all Linear-layer GEMM launches of a step taken together (algorithmic FLOPs only:
+            # the hi+lo weight split of precision mode 1 is NOT counted as work)
+            "roofline_linear_gemms": {"bound": "mfma", "kernel": "gemm_glds_kernel (all Linear layers of one step)",
+                                      "achieved": LINEAR_GFLOP_PER_CLIP * args.clips / max(prof["gemm"][0], 1e-9), "peak": MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": LINEAR_GFLOP_PER_CLIP * args.clips / max(prof["gemm"][0], 1e-9) / MFMA_PEAK_TFLOPS,
+                                      "ms_per_step": prof["gemm"][0], "launches_per_step": prof["gemm"][1]},
             "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
         }
         if not args.no_cpu_baseline and world == 1:

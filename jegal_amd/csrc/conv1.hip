@@ -40,7 +40,8 @@ struct Conv1Args {
     f16* out;             // pooled [nclip*P][43][78][64]
     f16* edge;            // [nclip*P][43][4][64]: vertically pooled conv column 32*j (j=1..4)
     long nstrips;         // nclip * P * 5
-    int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle
+    int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
+                          // 8 = no u8->fp16 conversion / LDS fill, 16 = no frame loads (timing experiments only)
 };
 
 namespace {
@@ -210,15 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         long t = 0;
         while (t < ntl) {
             __syncthreads();
-            if (t + 2 < ntl) issue(t + 2, RB);
-            if (t > 0) pool(t - 1);
-            if (t + 1 < ntl) cvt_write(RA, smem + (int)((t + 1) & 1) * TILE_BYTES);
+            if (t + 2 < ntl && !(a.dbg & 16)) issue(t + 2, RB);
+            if (t > 0 && !(a.dbg & 4)) pool(t - 1);
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RA, smem + (int)((t + 1) & 1) * TILE_BYTES);
             ++t;
             if (t >= ntl) break;
             __syncthreads();
-            if (t + 2 < ntl) issue(t + 2, RA);
-            pool(t - 1);
-            if (t + 1 < ntl) cvt_write(RB, smem + (int)((t + 1) & 1) * TILE_BYTES);
+            if (t + 2 < ntl && !(a.dbg & 16)) issue(t + 2, RA);
+            if (!(a.dbg & 4)) pool(t - 1);
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RB, smem + (int)((t + 1) & 1) * TILE_BYTES);
             ++t;
         }
         __syncthreads();                       // the MFMA waves have finished the last tile

@@ -276,6 +276,33 @@ def test_gesture_only_full_length_vs_oracle(engine, models, oracle_sd):
             assert r < TOL and mx < TOL
 
 
+def test_precision_modes(oracle_sd):
+    """hi+lo (W2) and bias-corrected (default) weights both hold the 1e-3 bound on a fresh clip; plain fp16
+    is measurably worse (it is what the two remedies exist for); re-calibrating on real clips keeps the bound."""
+    from jegal_amd._lib import Engine, PREC_FP16, PREC_FP16_W2, PREC_FP16_BC
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    gsd, jsd = oracle_sd
+    T = 20
+    frames = synth.synth_frames(4242, 1, T)
+    with torch.no_grad():
+        f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[0].astype(np.float32) / np.float32(255.0)))
+        ref = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
+    err = {}
+    for mode in (PREC_FP16, PREC_FP16_W2, PREC_FP16_BC):
+        e = Engine(0, precision=mode)
+        GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+        JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+        err[mode] = rel(e.extract_gesture(torch.from_numpy(frames).cuda())[0], ref)
+        if mode == PREC_FP16_BC:
+            e.calibrate(torch.from_numpy(synth.synth_frames(99, 2, 12)).cuda())       # user-supplied calibration clips
+            err["recal"] = rel(e.extract_gesture(torch.from_numpy(frames).cuda())[0], ref)
+        e.close()
+    print("precision modes:", err)
+    assert err[PREC_FP16_W2] < TOL and err[PREC_FP16_BC] < TOL and err["recal"] < TOL
+    assert err[PREC_FP16_BC] < err[PREC_FP16]
+
+
 def test_batch32_properties(engine, models):
     """Full BASELINE batch (32 x 150 frames): finite, unit-norm, deterministic, and independent of
     batch composition/chunking (clip b of the batch == the same clip run alone)."""
