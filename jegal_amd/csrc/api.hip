@@ -789,6 +789,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_ring")) { gemm_set_ring(value != 0); return JG_OK; }
+    if (!std::strcmp(name, "gemm_small_tile")) { gemm_set_small_tile(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_big_tile")) { gemm_set_big_tile(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_counted")) { gemm_set_counted(value); return JG_OK; }
     if (!std::strcmp(name, "gemm_persistent")) { gemm_set_persistent(value != 0); return JG_OK; }

@@ -513,10 +513,16 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
 }
 
 static bool g_big_tile = true;
+static bool g_small_tile = true;
 void gemm_set_big_tile(bool on) { g_big_tile = on; }
+void gemm_set_small_tile(bool on) { g_small_tile = on; }
 
 template <bool W2, bool CONV>
 static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
+    // small problems (the JEGAL branch: M = B*T = 4800 tokens) would leave most CUs idle with 256-row tiles:
+    // 128x128 tiles (32x64 wave tiles) give 4x the workgroups
+    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (g_small_tile && tiles256 < 200) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
     if constexpr (!W2) {
         if (g_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
     }
@@ -786,7 +792,7 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);
-    if (g_use_glds && a.K % 64 == 0 && a.M >= 256 && a.lda % 8 == 0 && a.ldw % 8 == 0) {
+    if (g_use_glds && a.K % 64 == 0 && a.M >= 128 && a.lda % 8 == 0 && a.ldw % 8 == 0) {
         if (g_use_ring) return w2 ? launch_ring<true, false>(a, s) : launch_ring<false, false>(a, s);
         return w2 ? launch_glds<true, false>(a, s) : launch_glds<false, false>(a, s);
     }
