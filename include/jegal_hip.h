@@ -84,6 +84,9 @@ int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B
 /* forward_audio (jegal.py:105-113): mel (B,Tm,80) fp32 -> out (B,Ta,256) fp32, Ta = jg_audio_len(Tm). */
 int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out);
 int jg_audio_len(int Tm);
+/* wav2filterbanks (utils/audio_utils.py:28-66): wav (B,n_samples) fp32 (int16 scale, NOT normalised: audio_utils.py:20-25),
+ * mel_basis (80,257) fp32 = librosa.filters.mel(sr=16000,n_fft=512,n_mels=80,fmin=0,fmax=8000) -> out (B, n_samples/160, 80) log-mel. */
+int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out);
 /* forward_text (jegal.py:95-103): states (B,L,768) fp32 (XLM-R last_hidden_state), mask (B,L) -> (B,L,256). */
 int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, int L, float* out);
 /* word pooling (jegal.py:174-180,189-195,233-239): for each int32 triplet (start_row,end_row_excl,dst_row)

@@ -36,6 +36,7 @@ _SIGS = {
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
+    "jg_logmel": [_P, _P, _I, _I, _P, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
     "jg_fuse_content": [_P, _P, _I, _P],
@@ -260,6 +261,16 @@ class Engine:
             raise ValueError("mel must have 80 bands")
         out = torch.empty((B, self.audio_len(Tm), 256), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_jegal_audio(self.h, _ptr(mel), B, Tm, _ptr(out)))
+        return out
+
+    def logmel(self, wav, mel_basis):
+        """wav (B,n) fp32 (int16 scale) -> log-mel (B, n//160, 80)."""
+        self._bind_stream()
+        wav = self._f32(wav)
+        mb = self._f32(mel_basis)
+        B, n = wav.shape
+        out = torch.empty((B, n // 160, 80), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_logmel(self.h, _ptr(wav), B, n, _ptr(mb), _ptr(out)))
         return out
 
     def jegal_text(self, states, mask=None):

@@ -890,6 +890,12 @@ int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out) {
     return jegal_audio_impl(h, mel, B, Tm, out);
 }
 
+int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out) {
+    if (!h) return JG_ERR_ARG;
+    if (!wav || !mel_basis || !out || B <= 0 || n_samples < 160) JG_FAIL(h, JG_ERR_ARG, "bad logmel arguments");
+    return timed(h, JG_ST_MISC, [&] { return launch_logmel(wav, B, n_samples, mel_basis, out, h->stream); });
+}
+
 int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
     if (!h) return JG_ERR_ARG;
     if (!states || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");

@@ -71,6 +71,7 @@ hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, h
 hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
+hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s);
 hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipStream_t s);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,

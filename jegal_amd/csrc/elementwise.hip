@@ -377,3 +377,56 @@ hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipS
     hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, out);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Log-mel front-end (utils/audio_utils.py:28-66): torch.stft(n_fft 512, hop 160, hann(320) centred in the
+// 512 window, center=True / reflect padding, onesided) -> drop the last frame -> |X| -> mel_basis (80x257) ->
+// log(. + 1e-20).  One block per frame: the windowed 512-sample segment and a 512-entry twiddle table live in
+// LDS, thread f computes bin f (and f+256) by direct DFT in fp32 (316 MFLOP per 150-frame clip: not worth an FFT),
+// then threads 0..79 do the mel dot products.
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, int n_samples, int n_frames,
+                                                     const float* __restrict__ mel_basis, float* __restrict__ out) {
+    __shared__ float seg[512];
+    __shared__ float tc[512], ts[512];
+    __shared__ float mag[257];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* x = wav + (long)b * n_samples;
+    for (int n = tid; n < 512; n += 256) {
+        float w = 0.f;
+        if (n >= 96 && n < 416) w = 0.5f - 0.5f * cosf(6.283185307179586f * (float)(n - 96) / 320.f);
+        int i = t * 160 + n - 256;
+        if (i < 0) i = -i;
+        if (i >= n_samples) i = 2 * (n_samples - 1) - i;
+        i = i < 0 ? 0 : i;
+        seg[n] = w * x[i];
+        float sn, cs;
+        sincosf(6.283185307179586f * (float)n / 512.f, &sn, &cs);
+        tc[n] = cs;
+        ts[n] = sn;
+    }
+    __syncthreads();
+    for (int f = tid; f < 257; f += 256) {
+        float re = 0.f, im = 0.f;
+        int ph = 0;
+        for (int n = 0; n < 512; ++n) {
+            re += seg[n] * tc[ph];
+            im -= seg[n] * ts[ph];
+            ph = (ph + f) & 511;
+        }
+        mag[f] = sqrtf(re * re + im * im);
+    }
+    __syncthreads();
+    if (tid < 80) {
+        const float* mb = mel_basis + tid * 257;
+        float acc = 0.f;
+        for (int f = 0; f < 257; ++f) acc += mb[f] * mag[f];
+        out[((long)b * n_frames + t) * 80 + tid] = logf(acc + 1e-20f);
+    }
+}
+
+hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s) {
+    const int n_frames = n_samples / 160;      // 1 + n/160 STFT frames, last one dropped (audio_utils.py:46)
+    if (B <= 0 || n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(logmel_kernel, dim3(n_frames, B), dim3(256), 0, s, wav, n_samples, n_frames, mel_basis, out);
+    return hipGetLastError();
+}

@@ -374,6 +374,20 @@ def similarity_cos(query_emb, data_emb, temp=0.07):
     return torch.softmax(sim / temp, dim=0).numpy()
 
 
+# --------------------------------------------------------------------------- audio front-end
+
+def wav2filterbanks(wav, mel_basis):
+    """utils/audio_utils.py:28-66 with torch.stft on the CPU.  `mel_basis` (80,257) must be supplied: the
+    reference takes it from librosa.filters.mel, which is third-party and absent (parity unpinned)."""
+    wav = _t(wav).float()
+    spect = torch.stft(wav, return_complex=True, n_fft=512, hop_length=160, win_length=320,
+                       window=torch.hann_window(320), center=True, pad_mode="reflect", normalized=False, onesided=True)
+    spect = torch.view_as_real(spect)[:, :, :-1, :]
+    mag = torch.norm(spect, dim=-1)
+    feats = torch.log(torch.matmul(_t(mel_basis).float(), mag) + 1e-20)
+    return feats.permute(0, 2, 1).contiguous()
+
+
 # --------------------------------------------------------------------------- text file
 
 def preprocess_text(text):

@@ -276,6 +276,30 @@ def test_gesture_only_full_length_vs_oracle(engine, models, oracle_sd):
             assert r < TOL and mx < TOL
 
 
+def test_logmel_frontend(engine):
+    """STFT + mel + log on the GPU vs torch.stft on the CPU (same mel basis; the basis itself restates
+    librosa's published algorithm and is unpinned).  Sizes of the reference's samples: 34691 samples -> 216 frames."""
+    from jegal_amd import audio
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal((2, 34691)) * 3000).astype(np.float32)
+    wav[1] *= np.linspace(0.0, 1.0, 34691, dtype=np.float32)
+    feats, _, _, mb = audio.wav2filterbanks(torch.from_numpy(wav).cuda(), engine=engine)
+    assert feats.shape == (2, 216, 80)
+    ref = O.wav2filterbanks(wav, mb.cpu())
+    assert float((feats.cpu() - ref).abs().max()) < 2e-3
+    assert rel(feats, ref) < 1e-5
+    basis = audio.mel_filterbank()
+    assert basis.shape == (80, 257) and (basis >= 0).all() and (basis.sum(1) > 0).all()
+    # the CNN consumes it: 216 mel frames -> 54 audio steps (SURVEY section 4)
+    assert engine.audio_len(216) == 54
+    # BASELINE configs[0] plumbing: the reference's own samples/sample1.wav (data fixture) -> 216 log-mel frames
+    wav1 = audio.load_wav(os.path.join(os.path.dirname(__file__), "golden", "sample1.wav")).astype("float32")
+    assert wav1.shape == (34691,)
+    f1, _, _, _ = audio.wav2filterbanks(torch.from_numpy(wav1)[None].cuda(), engine=engine)
+    assert f1.shape == (1, 216, 80)
+    assert rel(f1, O.wav2filterbanks(wav1[None], mb.cpu())) < 1e-5
+
+
 def test_precision_modes(oracle_sd):
     """hi+lo (W2) and bias-corrected (default) weights both hold the 1e-3 bound on a fresh clip; plain fp16
     is measurably worse (it is what the two remedies exist for); re-calibrating on real clips keeps the bound."""
