@@ -345,6 +345,35 @@ def test_batch32_properties(engine, models):
     assert rel(c, a[:7]) < 1e-5
 
 
+def test_vta_config3_full_batch(engine, models, oracle_sd):
+    """BASELINE configs[2]: batch 64, tri-modal (mel (64,600,80) ~ N(8,2.5), text states
+    (64,12,768), 10 words with boundaries [w_i, 15i, 15i+10]).  Shapes / finiteness on the whole batch, content
+    and gesture embeddings of 2 clips against the oracle."""
+    gs, jg = models
+    _, jsd = oracle_sd
+    B, T, W = 64, 150, 10
+    frames = torch.from_numpy(synth.synth_frames(1234, B, T)).cuda()
+    feats = torch.cat([gs.extract_clip_feats(frames[i:i + 32]) for i in range(0, B, 32)])
+    mel = synth.synth_mel(1235, B, 4 * T)
+    states, tmask, ids, offs = synth.synth_text(1236, B, W)
+    wbs = synth.synth_boundaries(B, W)
+    tbatch = [[w[0] for w in wb] for wb in wbs]
+    pack = (torch.from_numpy(states), torch.from_numpy(tmask), tbatch, ids, offs)
+    g, c = jg.forward_inference(visual_feats=feats, visual_mask=torch.ones(B, T), text=pack, audio=torch.from_numpy(mel),
+                                audio_mask=torch.ones(B, T), word_boundaries=wbs)
+    assert g.shape == (B, T, 512) and c.shape == (B, W, 512)
+    assert torch.isfinite(g).all() and torch.isfinite(c).all()
+    gn, cn = engine.l2norm(g), engine.l2norm(c)
+    for b in (0, 63):
+        p1 = (states[b:b + 1], tmask[b:b + 1], tbatch[b:b + 1], ids[b:b + 1], offs[b:b + 1])
+        with torch.no_grad():
+            rg, rc = O.jegal_forward_inference(jsd, visual_feats=feats[b:b + 1].cpu(), visual_mask=torch.ones(1, T), text=p1,
+                                               audio=torch.from_numpy(mel[b:b + 1]), audio_mask=None, word_boundaries=wbs[b:b + 1])
+        eg, ec = rel(gn[b], O.l2_normalize(rg[0])), rel(cn[b], O.l2_normalize(rc[0]))
+        print(f"vta clip {b}: gesture rel {eg:.3e} content rel {ec:.3e}")
+        assert eg < TOL and ec < TOL
+
+
 def test_ragged_batch_padding(models):
     """Zero-padded clips + key mask (dataset.py:336-340 contract): valid rows of a padded batch equal
     the clip run alone."""
