@@ -73,6 +73,8 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, 
 /* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,
  * pad = temporal edge padding (12 for clips, 0 for a raw 25-frame window) -> out (B*(T+2*pad-4),43,78,64) fp16 NHWC. */
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16);
+/* Tuning aid: ms per launch of the production GEMM for a shape (mode bit0 hi+lo weights, bit1 fp32 residual in/out, bit2 ReLU). */
+int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms);
 /* Drop-in for GestSync.forward_vid(x, return_feats) (gestsync.py:148-162): x (N,3,25,270,480) fp32
  * -> out (N,1024,21) fp32, optional out_conv (N,512,21) fp32 (NULL to skip). */
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv);

@@ -33,6 +33,7 @@ _SIGS = {
     "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
     "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
+    "jg_debug_gemm": [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
@@ -203,6 +204,12 @@ class Engine:
         out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
         return out
+
+    def debug_gemm(self, M, N, K, mode=0, iters=10):
+        self._bind_stream()
+        ms = ctypes.c_double()
+        self._ck(self.lib.jg_debug_gemm(self.h, M, N, K, mode, iters, ctypes.byref(ms)))
+        return ms.value
 
     def debug_conv1_pool(self, frames_u8, pad):
         """conv1+BN+ReLU+maxpool only: (B,T,270,480,3) u8 -> (B*(T+2*pad-4),43,78,64) fp16 NHWC."""

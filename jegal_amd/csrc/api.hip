@@ -789,6 +789,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_ring")) { gemm_set_ring(value != 0); return JG_OK; }
+    if (!std::strcmp(name, "gemm_tall_tile")) { gemm_set_tall_tile(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_small_tile")) { gemm_set_small_tile(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_big_tile")) { gemm_set_big_tile(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_counted")) { gemm_set_counted(value); return JG_OK; }
@@ -866,6 +867,45 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     Epi e; e.relu = 1; e.scale = h->c1_scale255; e.out16 = o1;
     RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
     return timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, static_cast<f16*>(out_f16), (int)NF, 88, 158, 64, h->stream); });
+}
+
+// Tuning aid: time `iters` launches of the production GEMM on garbage operands of a given shape.
+// mode bit 0: hi+lo weights, bit 1: fp32 residual in/out (else fp16 out), bit 2: ReLU.  Returns ms per launch in *ms.
+int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms) {
+    if (!h || !ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return JG_ERR_ARG;
+    h->ws.reset();
+    f16 *A, *Wh, *Wl, *o16;
+    float *bias, *x32;
+    RET(wsalloc(h, (size_t)M * K, &A));
+    RET(wsalloc(h, (size_t)N * K, &Wh));
+    RET(wsalloc(h, (size_t)N * K, &Wl));
+    RET(wsalloc(h, (size_t)M * N, &o16));
+    RET(wsalloc(h, (size_t)M * N, &x32));
+    RET(wsalloc(h, (size_t)N, &bias));
+    HIPCHK(h, hipMemsetAsync(A, 0x3c, (size_t)M * K * 2, h->stream));
+    HIPCHK(h, hipMemsetAsync(Wh, 0x2c, (size_t)N * K * 2, h->stream));
+    HIPCHK(h, hipMemsetAsync(Wl, 0x1c, (size_t)N * K * 2, h->stream));
+    HIPCHK(h, hipMemsetAsync(bias, 0, (size_t)N * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(x32, 0, (size_t)M * N * 4, h->stream));
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = K; a.Wh = Wh; a.Wl = (mode & 1) ? Wl : nullptr; a.ldw = K;
+    a.M = M; a.N = N; a.K = K; a.bias = bias; a.ldc = N; a.relu = (mode >> 2) & 1;
+    if (mode & 2) { a.res = x32; a.ldr = N; a.out32 = x32; } else { a.out16 = o16; }
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, launch_gemm(a, false, h->stream));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(a, false, h->stream));
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ms = t / iters;
+    return JG_OK;
 }
 
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv) {

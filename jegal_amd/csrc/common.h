@@ -51,6 +51,7 @@ void gemm_set_persistent(bool on);
 void gemm_set_counted(int on);
 void gemm_set_big_tile(bool on);
 void gemm_set_small_tile(bool on);
+void gemm_set_tall_tile(bool on);
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);

@@ -357,28 +357,36 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             const char* sX = smem + (kt & 1) * STAGE;
             const char* sWh = sX + XB;
             const char* sWl = sWh + WB;
+            // Fragment schedule pinned by hand: the 4 weight fragments of a k-step, then the activation fragments
+            // two ahead of the MFMAs that use them.  Left to itself hipcc hoists all 12 reads of a k-step in
+            // front of one s_waitcnt lgkmcnt(0), i.e. the MFMA pipe idles for a full LDS latency four times per
+            // k-tile and 48 VGPRs of fragments are live (no room to overlap anything).
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int choff = ((kk * 4 + fq) ^ fsw) << 4;
-                f16x8 wf[4], wl[4], xf[MI];
+                auto ldx = [&](int j) -> f16x8 {
+                    return *reinterpret_cast<const f16x8*>(sX + (wm * (16 * MI) + j * 16 + frow) * 128 + choff);
+                };
+                f16x8 wf[4], wl[4], xq[3];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = wn * 64 + i * 16 + frow;
                     wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
                     if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
                 }
+                xq[0] = ldx(0);
+                xq[1] = ldx(1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
-                    const int row = wm * (16 * MI) + j * 16 + frow;
-                    xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 128 + choff);
-                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                        if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
+                        if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xq[j % 3], acc[i][j], 0, 0, 0);
                     }
+                    if (j + 2 < MI) xq[(j + 2) % 3] = ldx(j + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __syncthreads();     // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
         }
@@ -514,8 +522,10 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
 
 static bool g_big_tile = true;
 static bool g_small_tile = true;
+static bool g_tall_tile = true;
 void gemm_set_big_tile(bool on) { g_big_tile = on; }
 void gemm_set_small_tile(bool on) { g_small_tile = on; }
+void gemm_set_tall_tile(bool on) { g_tall_tile = on; }
 
 template <bool W2, bool CONV>
 static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
@@ -525,6 +535,9 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     if (g_small_tile && tiles256 < 200) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
     if constexpr (!W2) {
         if (g_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
+        // N = 128 (conv2): 512x128 block tile, the whole 160 KiB of LDS -- the activation side dominates the
+        // L2->LDS traffic there, a taller tile halves the weight re-reads per activation byte
+        if (g_tall_tile && a.N == 128 && a.M >= 512 * 256) return launch_glds_cfg<false, CONV, 8, 4, 2>(a, s);
     }
     return launch_glds_cfg<W2, CONV, 4, 4, 2>(a, s);
 }
