@@ -73,6 +73,7 @@ struct jg_handle {
     bool gs_calibrated = false, jg_calibrated = false;
     std::vector<Lin*> bc_layers;
     int chunk = 8;
+    bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     std::map<std::string, HostTensor> host;
@@ -346,6 +347,8 @@ struct Epi {
     f16* out16 = nullptr;
     long ldc = 0;
     int relu = 0;
+    const LNp* ln = nullptr;      // fused residual + LayerNorm epilogue (when the GEMM can: see gemm_ln_fusable)
+    int ln_flavour = LN_STD;
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -359,6 +362,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
     a.out32 = e.out32; a.out16 = e.out16; a.ldc = e.ldc ? e.ldc : L.N;
     a.relu = e.relu;
+    if (e.ln) { a.ln_w = e.ln->w; a.ln_b = e.ln->b; a.ln_flavour = e.ln_flavour; }
     const bool conv = g != nullptr;
     if (h->calib && L.bc && !conv) {
         Lin& Lm = const_cast<Lin&>(L);
@@ -442,15 +446,25 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S) {
         e.out16 = qkv;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
         RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
-        Epi r;
-        r.res = x32; r.ldr = 512; r.out32 = x32;
-        RET(gemm(h, JG_ST_GEMM, att, 512, M, L.out, r));
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, 512, LN_STD, 0, x32, x16, h->stream); }));
+        // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue when the
+        // weights are single fp16 (row-wide 128x512 tiles); hi+lo weights (and the calibration pass) take the
+        // separate LayerNorm kernel.
+        auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
+            Epi r;
+            r.res = x32; r.ldr = 512; r.out32 = x32;
+            const bool w2 = (h->calib && W.bc) ? W.wl_calib != nullptr : W.wl != nullptr;
+            if (h->fuse_ln && !w2 && M >= 1024) {
+                r.out16 = x16; r.ln = &ln; r.ln_flavour = LN_STD;
+                return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
+            }
+            RET(gemm(h, JG_ST_GEMM, A, lda, M, W, r));
+            return timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, ln.w, ln.b, M, 512, LN_STD, 0, x32, x16, h->stream); });
+        };
+        RET(proj_ln(att, 512, L.out, L.n1));
         Epi f;
         f.relu = 1; f.out16 = hid;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.ff1, f));
-        RET(gemm(h, JG_ST_GEMM, hid, 2048, M, L.ff2, r));
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, 512, LN_STD, 0, x32, x16, h->stream); }));
+        RET(proj_ln(hid, 2048, L.ff2, L.n2));
     }
     return JG_OK;
 }
@@ -786,6 +800,7 @@ int jg_set_chunk(jg_handle* h, int c) {
 int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!h || !name) return JG_ERR_ARG;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_ring")) { gemm_set_ring(value != 0); return JG_OK; }

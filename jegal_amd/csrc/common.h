@@ -37,6 +37,10 @@ struct GemmArgs {
     f16* out16;           // optional fp16 output
     long ldc;
     int relu;
+    // fused LayerNorm epilogue (row-wide tiles only, N == 512): out32/out16 receive LN(acc*scale + bias + res)
+    const float* ln_w;    // nullptr: no LayerNorm
+    const float* ln_b;
+    int ln_flavour;       // LN_STD / LN_ANNOTATED
 };
 
 enum { LN_STD = 0, LN_ANNOTATED = 1 };
@@ -44,6 +48,7 @@ enum { LN_STD = 0, LN_ANNOTATED = 1 };
 
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
+bool gemm_ln_fusable(const GemmArgs& a);
 void gemm_set_glds(bool on);
 void gemm_set_ring(bool on);
 void gemm_set_ring_cfg(int c);

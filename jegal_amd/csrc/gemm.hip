@@ -204,9 +204,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MI = 16-row MFMA tiles per wave along m (4: 64x64 wave tile, 8: 128x64); WM x WN waves.
 //   <4,4,2>: 256x128 block tile (hi+lo weights fit two LDS stages);  <8,2,4>: 256x256 block tile for single-fp16
 //   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
-template <bool W2, bool CONV, int MI, int WM, int WN>
+template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok) {
     static_assert(WM * WN == 8, "8 waves");
+    static_assert(!LNF || (WM == 1 && !W2), "fused LayerNorm needs a row-wide tile: all 8 waves side by side along n");
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr int XI = BM / 64, WI = BN / 64;            // LDS-DMA instructions (8 rows each) per wave per k-tile
     constexpr int XB = BM * 128, WB = BN * 128;
@@ -399,6 +400,100 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
 
+        if constexpr (LNF) {
+            // ---- fused residual + LayerNorm epilogue (gestsync.py:20: LN(x + sublayer(x)), eps 1e-5).
+            // The tile spans the whole row (BN == N == 512, wave wn owns columns wn*64..+63), so the row
+            // statistics are a shuffle over the 4 lanes of a row inside the wave plus an 8-way exchange through
+            // LDS (stage 1 of the ring is idle here: the next tile's first k-tile went to stage 0).
+            // Two-pass (mean, then centred variance) like nn.LayerNorm.  Saves the fp32 round trip of the
+            // pre-norm sum through HBM and the separate LayerNorm launch.
+            float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
+            const int nbase = cn0 + wn * 64 + fq * 4;
+            f32x4 scv[4], biv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                scv[i] = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nbase + i * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
+                biv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nbase + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            float rsum[MI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                int m = cm0 + j * 16 + frow;
+                m = m < a.M ? m : a.M - 1;
+                const int rr = a.res_mod ? (m % a.res_mod) : m;
+                const float* rp = a.res + (long)rr * a.ldr + nbase;
+                float sj = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = acc[i][j] * scv[i] + biv[i];
+                    if (a.res) v += *reinterpret_cast<const f32x4*>(rp + i * 16);
+                    acc[i][j] = v;
+                    sj += (v.x + v.y) + (v.z + v.w);
+                }
+                sj += __shfl_xor(sj, 16, 64);
+                sj += __shfl_xor(sj, 32, 64);
+                rsum[j] = sj;
+            }
+            if (fq == 0) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j) red[wn * BM + j * 16 + frow] = rsum[j];
+            }
+            __syncthreads();
+            float mean[MI], rsq[MI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) tsum += red[w * BM + j * 16 + frow];
+                mean[j] = tsum * (1.f / BN);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 d = acc[i][j] - mean[j];
+                    acc[i][j] = d;
+                    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                rsq[j] = q;
+            }
+            if (fq == 0) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j) red[(8 + wn) * BM + j * 16 + frow] = rsq[j];
+            }
+            __syncthreads();
+            f32x4 lw[4], lb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lw[i] = *reinterpret_cast<const f32x4*>(a.ln_w + nbase + i * 16);
+                lb[i] = *reinterpret_cast<const f32x4*>(a.ln_b + nbase + i * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                float tq = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) tq += red[(8 + w) * BM + j * 16 + frow];
+                const float inv = a.ln_flavour == LN_STD ? 1.f / sqrtf(tq * (1.f / BN) + 1e-5f)
+                                                         : 1.f / (sqrtf(tq * (1.f / (BN - 1))) + 1e-6f);
+                const int m = cm0 + j * 16 + frow;
+                if (m < a.M) {
+                    const long mo = (long)m * a.ldc + nbase;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 y = acc[i][j] * inv * lw[i] + lb[i];
+                        if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = y;
+                        if (a.out16) {
+                            f16x4 hh = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
+                            *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = hh;
+                        }
+                    }
+                }
+            }
+            __syncthreads();          // red[] is read; stage 1 may be refilled by the next tile's k-tile 1
+            if (nbid < 0) break;
+            counted = false;
+            continue;
+        }
         // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile.
         // Interior tiles take a branch-free path: ALL residual / scale / bias loads are issued first, then
         // the math, then all stores.  (Per-element `if (m < M) load` made hipcc branch around every load
@@ -518,6 +613,35 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
     const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
     hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted);
     return hipGetLastError();
+}
+
+template <bool CONV>
+static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t lds = 2 * (size_t)(128 * 128 + 512 * 128);          // 160 KiB: the whole LDS
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<false, CONV, 8, 1, 8, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const f16* z = zero_page();
+    if (!z) return hipErrorOutOfMemory;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int tiles = (a.M + 127) / 128;
+    const int grid = tiles < num_cu ? tiles : num_cu;
+    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, 0);
+    return hipGetLastError();
+}
+
+bool gemm_ln_fusable(const GemmArgs& a) {
+    return a.Wl == nullptr && a.N == 512 && a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && !a.relu;
 }
 
 static bool g_big_tile = true;
@@ -794,6 +918,10 @@ void gemm_set_ring(bool on) { g_use_ring = on; }
 
 hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
+    if (a.ln_w) {
+        if (conv || !gemm_ln_fusable(a)) return hipErrorInvalidValue;
+        return launch_glds_ln<false>(a, s);
+    }
     const bool w2 = a.Wl != nullptr;
     const bool narrow = a.N <= 64;
     if (conv) {
