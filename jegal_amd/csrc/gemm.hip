@@ -17,7 +17,9 @@
 // * CONV: the activation "row" m is an output pixel (img,oh,ow) of an NHWC tensor and
 //   k = (kh,kw,c); out-of-image taps are zero-filled at staging time.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 template <int WM, int WN, bool CONV, bool W2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -205,7 +207,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   <4,4,2>: 256x128 block tile (hi+lo weights fit two LDS stages);  <8,2,4>: 256x256 block tile for single-fp16
 //   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
 template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok) {
+__global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
     static_assert(!LNF || (WM == 1 && !W2), "fused LayerNorm needs a row-wide tile: all 8 waves side by side along n");
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
@@ -307,26 +309,47 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     };
 
     const int nk = (a.K + 63) / 64;
-    const int nstores = (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);     // epilogue store instructions per wave (interior tile)
 
     int round = 0;
     int bid = tile_of(0);
     if (bid < 0) return;
     setup(bid);
     stage(0, 0);
-    bool counted = false;      // the k-tile-0 DMA of this tile is older than exactly `nstores` epilogue stores
+    if (const int stagger = counted_ok >> 8) {
+        // De-phase the workgroups: left alone all CUs reach their epilogue together and the store burst of a
+        // whole round (G tiles) hits HBM at once while the MFMA pipes wait for it.  The highest block ids get
+        // the longest delay -- they are the ones that run one tile fewer in the last round.
+        const int ph = (int)(((long)blockIdx.x * 4) / G);
+        if (ph) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)(ph * stagger)) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    counted_ok &= 1;
+    // debug timeline (gemm_timeline option): wave 0 of workgroup 0 / G-1 stamps s_memrealtime at the phase edges
+    int tli = 0;
+    const bool tl_on = tl != nullptr && wave == 0 && (blockIdx.x == 0 || blockIdx.x == G - 1);
+    unsigned long long* tlp = tl + (blockIdx.x == 0 ? 0 : 512);
+    auto mark = [&]() {
+        if (tl_on && tli < 512) {
+            const unsigned long long c = wall_clock64();
+            if (lane == 0) tlp[tli] = c;
+            ++tli;
+        }
+    };
+    int pending = 0;           // the k-tile-0 DMA of this tile is older than exactly `pending` epilogue stores (0: unknown)
     while (true) {
         // The first k-tile of this tile was issued BEFORE the previous tile's epilogue stores, so it can be
         // retired with a counted wait that leaves those stores in flight: the store burst (and its HBM
         // latency) overlaps this tile's first MFMAs instead of idling the CU.
-        if (counted && nstores == 16) {
-            wait_vmcnt<16>();
-        } else if (counted && nstores == 32) {
-            wait_vmcnt<32>();
-        } else {
-            wait_vmcnt<0>();
+        switch (pending) {
+            case 8: wait_vmcnt<8>(); break;
+            case 16: wait_vmcnt<16>(); break;
+            case 32: wait_vmcnt<32>(); break;
+            default: wait_vmcnt<0>(); break;
         }
         __builtin_amdgcn_s_barrier();
+        mark();     // 0: tile start (first k-tile landed)
         const int cn0 = n0, cm0 = m0;
         const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
@@ -392,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             __syncthreads();     // drains the LDS-DMA of tile kt+1 (vmcnt(0)) and fences the reads of tile kt
         }
 
+        mark();     // 1: k loop done
         // next tile: issue its first k-tile now, BEFORE the epilogue's stores
         const int nbid = tile_of(++round);
         if (nbid >= 0) {
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             stage(0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
+        mark();     // 2: next tile's first DMA issued
 
         if constexpr (LNF) {
             // ---- fused residual + LayerNorm epilogue (gestsync.py:20: LN(x + sublayer(x)), eps 1e-5).
@@ -491,14 +516,63 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
             __syncthreads();          // red[] is read; stage 1 may be refilled by the next tile's k-tile 1
             if (nbid < 0) break;
-            counted = false;
+            pending = 0;
             continue;
         }
         // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile.
         // Interior tiles take a branch-free path: ALL residual / scale / bias loads are issued first, then
         // the math, then all stores.  (Per-element `if (m < M) load` made hipcc branch around every load
         // and wait vmcnt(0) after each one: 16 serial HBM round trips per tile, 1/3 of the Linear time.)
-        if (interior) {
+        // fp16-only outputs (qkv, linear1, the conv layers): transpose the tile through LDS so that every store
+        // instruction writes 8 rows x 128 contiguous bytes.  In the MFMA fragment layout a store instruction covers
+        // 16 rows x 32 B, and the CU's write path retires those at ~17 GB/s: 8-9 us per 256x256 tile, as long as the
+        // whole k loop at K = 512 (tools/store_pattern.hip, tools/gemm_timeline.py).  The scratch is this wave's
+        // slice of LDS stage 1, idle until the next tile's k-tile 1 is staged (after the barrier at the loop top);
+        // a wave's LDS instructions execute in order, so consecutive 16-row blocks reuse the same 2.3 KB.
+        constexpr int TP16 = 144;                        // row pitch: 16-B aligned, 36 banks -> conflict-free b64 writes
+        constexpr bool ROWS_OK = STAGE / 8 >= 16 * TP16;
+        const bool rows16 = ROWS_OK && interior && a.out16 && !a.out32 && !a.res && (a.ldc & 7) == 0;
+        if (rows16) {
+            char* tsc = smem + STAGE + wave * (16 * TP16);
+            f32x4 sc[4], bi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+                bi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (a.scale) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
+            }
+            f16* orow = a.out16 + (long)(cm0 + wm * (16 * MI) + (lane >> 3)) * a.ldc + cn0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = acc[i][j] * sc[i] + bi[i];
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                    *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
+                    *reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        } else if (interior) {
             f32x4 sc[4], bi[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -569,8 +643,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 }
             }
         }
+        mark();     // 3: epilogue issued
         if (nbid < 0) break;
-        counted = interior && counted_ok;
+        pending = !(interior && counted_ok) ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
     }
 }
 
@@ -578,6 +653,28 @@ static bool g_persistent = true;
 static int g_counted = 1;
 void gemm_set_persistent(bool on) { g_persistent = on; }
 void gemm_set_counted(int on) { g_counted = on; }
+static int g_stagger = 0;       // 10-ns ticks per phase (4 phases)
+void gemm_set_stagger(int ticks) { g_stagger = ticks; }
+static unsigned long long* g_tl = nullptr;
+void gemm_set_timeline(bool on) {
+    if (on && !g_tl) {
+        if (hipHostMalloc(&g_tl, 1024 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) g_tl = nullptr;
+    } else if (!on && g_tl) {
+        hipHostFree(g_tl);
+        g_tl = nullptr;
+    }
+}
+static void dump_timeline(hipStream_t s, const char* what) {
+    hipStreamSynchronize(s);
+    for (int b = 0; b < 2; ++b) {
+        const unsigned long long* t = g_tl + b * 512;
+        std::fprintf(stderr, "[gemm timeline %s wg %s] (100 MHz ticks -> us)\n", what, b ? "last" : "0");
+        for (int i = 0; i + 3 < 512 && t[i + 3]; i += 4) {
+            std::fprintf(stderr, "  tile %2d: kloop %6.2f  setup+dma-issue %5.2f  epilogue %5.2f  wait-next %5.2f\n", i / 4, (t[i + 1] - t[i]) * 0.01,
+                         (t[i + 2] - t[i + 1]) * 0.01, (t[i + 3] - t[i + 2]) * 0.01, t[i + 4] ? (t[i + 4] - t[i + 3]) * 0.01 : 0.0);
+        }
+    }
+}
 
 static const f16* zero_page() {
     static f16* z = nullptr;
@@ -611,7 +708,12 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const int tiles = mt * nt;
     const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted);
+    if (g_tl) {
+        hipStreamSynchronize(s);
+        std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (g_stagger << 8), g_tl);
+    if (g_tl) dump_timeline(s, CONV ? "conv" : "linear");
     return hipGetLastError();
 }
 
@@ -636,7 +738,7 @@ static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
     }
     const int tiles = (a.M + 127) / 128;
     const int grid = tiles < num_cu ? tiles : num_cu;
-    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, 0);
+    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, 0, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
