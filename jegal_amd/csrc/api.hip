@@ -434,7 +434,19 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
 }
 
 // post-norm transformer (gestsync.py:20-21) in place on x32/x16, M = nseq*21 tokens
-int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S) {
+// Whether the whole GestSync transformer of M tokens runs with residual+LayerNorm fused into the projection GEMMs.
+// All twelve projections must qualify (single-fp16 weights, not the calibration pass): the fused kernel keeps the
+// fp32 residual stream in its own tiled order (gemm.hip), so fused and unfused layers cannot be mixed.
+bool gs_fused_plan(const jg_handle* h, int M) {
+    if (!h->fuse_ln || h->calib || M < 1024) return false;
+    for (int l = 0; l < 6; ++l)
+        if (h->gs_layers[l].out.wl || h->gs_layers[l].ff2.wl) return false;
+    return true;
+}
+inline size_t pad128(size_t rows) { return (rows + 127) / 128 * 128; }
+
+// x32/x16 hold pad128(M) rows; with `tiled` x32 is the tiled residual stream (launch_window_gather(..., tiled = 1)).
+int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled) {
     const int M = nseq * S;
     f16 *qkv, *att, *hid;
     RET(wsalloc(h, (size_t)M * 1536, &qkv));
@@ -446,14 +458,12 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S) {
         e.out16 = qkv;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
         RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
-        // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue when the
-        // weights are single fp16 (row-wide 128x512 tiles); hi+lo weights (and the calibration pass) take the
-        // separate LayerNorm kernel.
+        // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue (row-wide
+        // 128x512 tiles, tiled fp32 residual stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
         auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
             Epi r;
             r.res = x32; r.ldr = 512; r.out32 = x32;
-            const bool w2 = (h->calib && W.bc) ? W.wl_calib != nullptr : W.wl != nullptr;
-            if (h->fuse_ln && !w2 && M >= 1024) {
+            if (tiled) {
                 r.out16 = x16; r.ln = &ln; r.ln_flavour = LN_STD;
                 return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
             }
@@ -489,10 +499,11 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
         const int nseq = nb * T, M = nseq * S;
         float* x32; f16 *x16, *hid, *mean16;
-        RET(wsalloc(h, (size_t)M * 512, &x32));
-        RET(wsalloc(h, (size_t)M * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, x32, x16, h->stream); }));
-        RET(gs_transformer(h, x32, x16, nseq, S));
+        const bool tiled = gs_fused_plan(h, M);
+        RET(wsalloc(h, pad128(M) * 512, &x32));
+        RET(wsalloc(h, pad128(M) * 512, &x16));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
+        RET(gs_transformer(h, x32, x16, nseq, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
         Epi f; f.relu = 1; f.out16 = hid;
@@ -520,10 +531,11 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
             RET(timed(h, JG_ST_MISC, [&] { return launch_transpose_tokens(conv, nb, S, 512, out_conv + (size_t)n0 * 512 * S, h->stream); }));
         const int M = nb * S;
         float *x32, *full; f16 *x16, *hid;
-        RET(wsalloc(h, (size_t)M * 512, &x32));
-        RET(wsalloc(h, (size_t)M * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, 0, x32, x16, h->stream); }));
-        RET(gs_transformer(h, x32, x16, nb, S));
+        const bool tiled = gs_fused_plan(h, M);
+        RET(wsalloc(h, pad128(M) * 512, &x32));
+        RET(wsalloc(h, pad128(M) * 512, &x16));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled, x32, x16, h->stream); }));
+        RET(gs_transformer(h, x32, x16, nb, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)M * 1024, &full));
         Epi f; f.relu = 1; f.out16 = hid;
@@ -896,8 +908,8 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
     RET(wsalloc(h, (size_t)M * K, &A));
     RET(wsalloc(h, (size_t)N * K, &Wh));
     RET(wsalloc(h, (size_t)N * K, &Wl));
-    RET(wsalloc(h, (size_t)M * N, &o16));
-    RET(wsalloc(h, (size_t)M * N, &x32));
+    RET(wsalloc(h, pad128(M) * N, &o16));
+    RET(wsalloc(h, pad128(M) * N, &x32));
     RET(wsalloc(h, (size_t)N, &bias));
     HIPCHK(h, hipMemsetAsync(A, 0x3c, (size_t)M * K * 2, h->stream));
     HIPCHK(h, hipMemsetAsync(Wh, 0x2c, (size_t)N * K * 2, h->stream));
@@ -909,6 +921,9 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
     a.A = A; a.lda = K; a.Wh = Wh; a.Wl = (mode & 1) ? Wl : nullptr; a.ldw = K;
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.ldc = N; a.relu = (mode >> 2) & 1;
     if (mode & 2) { a.res = x32; a.ldr = N; a.out32 = x32; } else { a.out16 = o16; }
+    if (mode & 8) {      // residual + LayerNorm fused (N = 512): gamma/beta = the zero bias vector, timing only
+        a.out16 = o16; a.ln_w = bias; a.ln_b = bias; a.ln_flavour = LN_STD;
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));

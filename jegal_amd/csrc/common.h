@@ -66,7 +66,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
                                f16* out_pooled, f16* edge, hipStream_t s);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
-hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift,
+hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s);
 hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,
                             int relu, float* out32, f16* out16, hipStream_t s);

@@ -94,7 +94,7 @@ hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int
 // shift/clamp: with edge padding the first 9 and last 9 padded-clip positions see five copies of the
 // same frame, so the conv stack is only evaluated for the T+4 distinct positions (shift = 8).
 __global__ void window_gather_kernel(const float* __restrict__ conv, const float* __restrict__ pe, int B, int P, int Twin,
-                                     int L, int D, int shift, float* __restrict__ x32, f16* __restrict__ x16) {
+                                     int L, int D, int shift, int tiled, float* __restrict__ x32, f16* __restrict__ x16) {
     const int dv = D / 4;
     const long total = (long)B * Twin * L * dv;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -108,17 +108,27 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
         pp = pp < 0 ? 0 : (pp > P - 1 ? P - 1 : pp);
         f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + pp) * D + d4 * 4);
         v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
-        *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
+        long o32 = idx * 4;
+        if (tiled) {
+            // fp32 residual stream in the fused GEMM+LayerNorm kernel's fragment order (gemm.hip, LNF epilogue):
+            // [row tile of 128][wave = col/64][j = row%128/16][i = col%64/16][lane = (col%16/4)*16 + row%16] float4
+            const long row = idx / dv;
+            const int col = d4 * 4;
+            const int rr = (int)(row & 127);
+            o32 = (row >> 7) * (128 * 512) + ((((col >> 6) * 8 + (rr >> 4)) * 4 + ((col & 63) >> 4)) * 64 + ((col & 15) >> 2) * 16 + (rr & 15)) * 4;
+        }
+        *reinterpret_cast<f32x4*>(x32 + o32) = v;
         f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
         *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
     }
 }
 
-hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift,
+hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s) {
+    if (tiled && D != 512) return hipErrorInvalidValue;
     const long total = (long)B * Twin * L * (D / 4);
     const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, shift, x32, x16);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, shift, tiled, x32, x16);
     return hipGetLastError();
 }
 

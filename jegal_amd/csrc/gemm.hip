@@ -337,6 +337,19 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             ++tli;
         }
     };
+    // LNF: the accumulators start from the fp32 residual, loaded in fragment order from the tiled residual stream
+    // (see the epilogue) one tile ahead, so its HBM latency hides behind the previous tile's stores.
+    f32x4 acc[4][MI];
+    auto res_tile = [&](const float* base, int tm0) -> const float* {
+        return base + (long)(tm0 / BM) * (BM * BN) + (long)wn * (MI * 4 * 256) + lane * 4;
+    };
+    if constexpr (LNF) {
+        const float* rp = res_tile(a.res, m0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(rp + (j * 4 + i) * 256);
+    }
     int pending = 0;           // the k-tile-0 DMA of this tile is older than exactly `pending` epilogue stores (0: unknown)
     while (true) {
         // The first k-tile of this tile was issued BEFORE the previous tile's epilogue stores, so it can be
@@ -346,6 +359,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             case 8: wait_vmcnt<8>(); break;
             case 16: wait_vmcnt<16>(); break;
             case 32: wait_vmcnt<32>(); break;
+            case 60: wait_vmcnt<60>(); break;
             default: wait_vmcnt<0>(); break;
         }
         __builtin_amdgcn_s_barrier();
@@ -356,12 +370,12 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         const int mb = cm0 + wm * (16 * MI) + frow;
         constexpr bool PREFETCH_RES = MI <= 4;        // 128x64 wave tiles have no registers to spare for it
 
-        f32x4 acc[4][MI], rs[4][PREFETCH_RES ? MI : 1];
+        f32x4 rs[4][PREFETCH_RES ? MI : 1];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!LNF) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (PREFETCH_RES) rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 
@@ -416,42 +430,45 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
 
         mark();     // 1: k loop done
-        // next tile: issue its first k-tile now, BEFORE the epilogue's stores
+        // next tile: issue its first k-tile now, BEFORE the epilogue's stores (LNF: inside its epilogue, see there)
         const int nbid = tile_of(++round);
         if (nbid >= 0) {
             setup(nbid);
-            stage(0, 0);
+            if (!LNF) stage(0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
         mark();     // 2: next tile's first DMA issued
 
         if constexpr (LNF) {
             // ---- fused residual + LayerNorm epilogue (gestsync.py:20: LN(x + sublayer(x)), eps 1e-5).
-            // The tile spans the whole row (BN == N == 512, wave wn owns columns wn*64..+63), so the row
-            // statistics are a shuffle over the 4 lanes of a row inside the wave plus an 8-way exchange through
-            // LDS (stage 1 of the ring is idle here: the next tile's first k-tile went to stage 0).
-            // Two-pass (mean, then centred variance) like nn.LayerNorm.  Saves the fp32 round trip of the
-            // pre-norm sum through HBM and the separate LayerNorm launch.
+            // The tile spans the whole row (BN == N == 512, wave wn owns columns wn*64..+63): row statistics are a
+            // shuffle over the 4 lanes of a row inside the wave plus an 8-way exchange through LDS (stage 1 is idle
+            // here).  Two-pass (mean, then centred variance) like nn.LayerNorm.
+            //
+            // The fp32 residual stream (a.res in, a.out32 out, normally the same buffer) is NOT row-major: it is
+            // stored in this kernel's own fragment order -- tile R = m/128, then [wave wn][j][i][lane] float4 --
+            // so every residual load and every fp32 store is one contiguous 1 KB per wave instruction, with no
+            // LDS transposition.  launch_window_gather(..., tiled) writes the initial stream in that order; nothing
+            // else reads it.  The residual of the NEXT tile is loaded straight into the accumulators as soon as
+            // the row block j of this tile has been stored (no spare registers, latency hidden behind the rest of
+            // the epilogue).  The fp16 copy (the next GEMM's activation operand) is row-major and goes through
+            // the LDS transposition like every fp16 output.  Whole 128-row tiles are written: out16 and the
+            // stream hold ceil(M/128)*128 rows.
+            constexpr int TP16 = 144;
+            constexpr int JD = 2;                                         // row block in front of which the next tile's DMA goes
             float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
+            char* tsc = smem + STAGE + 2 * 8 * BM * 4 + wave * (16 * TP16);
             const int nbase = cn0 + wn * 64 + fq * 4;
-            f32x4 scv[4], biv[4];
+            f32x4 biv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                scv[i] = a.scale ? *reinterpret_cast<const f32x4*>(a.scale + nbase + i * 16) : f32x4{1.f, 1.f, 1.f, 1.f};
-                biv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nbase + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < 4; ++i) biv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nbase + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
             float rsum[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                int m = cm0 + j * 16 + frow;
-                m = m < a.M ? m : a.M - 1;
-                const int rr = a.res_mod ? (m % a.res_mod) : m;
-                const float* rp = a.res + (long)rr * a.ldr + nbase;
                 float sj = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f32x4 v = acc[i][j] * scv[i] + biv[i];
-                    if (a.res) v += *reinterpret_cast<const f32x4*>(rp + i * 16);
+                    const f32x4 v = acc[i][j] + biv[i];
                     acc[i][j] = v;
                     sj += (v.x + v.y) + (v.z + v.w);
                 }
@@ -464,17 +481,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int j = 0; j < MI; ++j) red[wn * BM + j * 16 + frow] = rsum[j];
             }
             __syncthreads();
-            float mean[MI], rsq[MI];
+            float rsq[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 float tsum = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) tsum += red[w * BM + j * 16 + frow];
-                mean[j] = tsum * (1.f / BN);
+                const float mean = tsum * (1.f / BN);
                 float q = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 d = acc[i][j] - mean[j];
+                    const f32x4 d = acc[i][j] - mean;
                     acc[i][j] = d;
                     q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
                 }
@@ -493,30 +510,48 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 lw[i] = *reinterpret_cast<const f32x4*>(a.ln_w + nbase + i * 16);
                 lb[i] = *reinterpret_cast<const f32x4*>(a.ln_b + nbase + i * 16);
             }
+            float* o32 = const_cast<float*>(res_tile(a.out32, cm0));
+            const float* rnext = res_tile(a.res, m0);                      // m0 is already the next tile's
+            f16* orow = a.out16 + (long)(cm0 + (lane >> 3)) * a.ldc + cn0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
+                if (j == JD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nbid >= 0) stage(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 float tq = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) tq += red[(8 + w) * BM + j * 16 + frow];
                 const float inv = a.ln_flavour == LN_STD ? 1.f / sqrtf(tq * (1.f / BN) + 1e-5f)
                                                          : 1.f / (sqrtf(tq * (1.f / (BN - 1))) + 1e-6f);
-                const int m = cm0 + j * 16 + frow;
-                if (m < a.M) {
-                    const long mo = (long)m * a.ldc + nbase;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 y = acc[i][j] * inv * lw[i] + lb[i];
-                        if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = y;
-                        if (a.out16) {
-                            f16x4 hh = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
-                            *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = hh;
-                        }
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 y = acc[i][j] * inv * lw[i] + lb[i];
+                    *reinterpret_cast<f32x4*>(o32 + (j * 4 + i) * 256) = y;
+                    f16x4 hv = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
+                    *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
+                    *reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc) = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (nbid >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(rnext + (j * 4 + i) * 256);
                 }
             }
-            __syncthreads();          // red[] is read; stage 1 may be refilled by the next tile's k-tile 1
+            mark();     // 3: epilogue issued
             if (nbid < 0) break;
-            pending = 0;
+            // the loop-top barrier fences red[]/tsc against the next tile's k-tile 1 (staged after it)
+            pending = counted_ok ? (MI - JD) * 10 : 0;
             continue;
         }
         // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile.
@@ -738,12 +773,18 @@ static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
     }
     const int tiles = (a.M + 127) / 128;
     const int grid = tiles < num_cu ? tiles : num_cu;
-    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, 0, (unsigned long long*)nullptr);
+    if (g_tl) {
+        hipStreamSynchronize(s);
+        std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
+    }
+    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, g_counted | (g_stagger << 8), g_tl);
+    if (g_tl) dump_timeline(s, "linear+LN");
     return hipGetLastError();
 }
 
 bool gemm_ln_fusable(const GemmArgs& a) {
-    return a.Wl == nullptr && a.N == 512 && a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && !a.relu;
+    return a.Wl == nullptr && a.N == 512 && a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && !a.relu && !a.scale &&
+           a.res && a.res_mod == 0 && a.out32 && a.out16 && a.ldc == 512;
 }
 
 static bool g_big_tile = true;
