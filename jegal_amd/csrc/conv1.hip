@@ -30,7 +30,9 @@
 // Neighbouring workgroups work on the strips of one position at the same time, so its 5 frames
 // (1.9 MB) stay in the XCD L2s; a frame is re-read for 5 positions.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 struct Conv1Args {
     const uint8_t* src;   // [nclip][T][270][480][3]
@@ -39,9 +41,11 @@ struct Conv1Args {
     float scale;          // uniform epilogue scale (1/255 for u8 sources; BN scale is folded into Wd)
     f16* out;             // pooled [nclip*P][43][78][64]
     f16* edge;            // [nclip*P][43][4][64]: vertically pooled conv column 32*j (j=1..4)
-    long nstrips;         // nclip * P * 5
+    int nstrips;          // nclip * P * 5
+    float invP;           // 1/P for the position -> (clip, frame) split
+    unsigned long long* tl;   // debug timeline (env JG_CONV1_TL): 100 MHz stamps of workgroup 0, waves 0 and 4
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
-                          // 8 = no u8->fp16 conversion / LDS fill, 16 = no frame loads (timing experiments only)
+                          // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
 };
 
 namespace {
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long G = gridDim.x;
-    // The BN-folded bias rides in the GEMM: element 15 of every pixel slot is 1.0 and the weight panel
+    // The BN-folded bias rides in the GEMM: element 15 of every pixel slot is "1.0" (2^-24, the
+    // same scale as the pixel values, see cvt_write) and the weight panel
     // holds shift/scale (hi+lo fp16 pair) at [slot 0][c][15] and [slot 1][c][15] -- no accumulator
     // init read, no global load in the epilogue:  out = relu(acc * scale).
 
@@ -85,13 +90,36 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // XCD gets ONE contiguous range of strips (= whole clips) and its workgroups walk it together --
     // the 5 frames of a position are then fetched into that L2 once instead of into all eight.
     // local tile t of this workgroup -> strip s_lo + (t/22)*GX, row tile t%22
-    const long xcd = blockIdx.x & 7, xidx = blockIdx.x >> 3;
-    const long GX = (G + 7 - xcd) >> 3;                                 // workgroups on this XCD
-    const long per = (a.nstrips + 7) >> 3;
-    const long r_lo = xcd * per, r_hi = (r_lo + per < a.nstrips) ? r_lo + per : a.nstrips;
-    const long s_lo = r_lo + xidx;
-    const long my_strips = (s_lo < r_hi && GX > 0) ? (r_hi - s_lo + GX - 1) / GX : 0;
-    const long ntl = my_strips * ROW_TILES;
+    // All of this index math is 32-bit and incremental: the first version decoded every tile id with 64-bit
+    // divisions (t/22, strip/5, nf/P) in both issue() and pool() -- ~1.2 us of VALU per tile on the loader waves,
+    // which made THEM the critical path (tools/conv1_ablate.py, JG_CONV1_TL=1).
+    const int G32 = (int)G;
+    const int xcd = blockIdx.x & 7, xidx = blockIdx.x >> 3;
+    const int GX = (G32 + 7 - xcd) >> 3;                                 // workgroups on this XCD
+    const int per = (a.nstrips + 7) >> 3;
+    const int r_lo = xcd * per, r_hi = (r_lo + per < a.nstrips) ? r_lo + per : a.nstrips;
+    const int s_lo = r_lo + xidx;
+    const int my_strips = (s_lo < r_hi && GX > 0) ? (r_hi - s_lo + GX - 1) / GX : 0;
+    const int ntl = my_strips * ROW_TILES;
+    // local tile t -> (strip, row tile); advanced one tile at a time
+    struct Pos {
+        int strip, rt;
+    };
+    auto advance = [&](Pos& q) {
+        if (++q.rt == ROW_TILES) {
+            q.rt = 0;
+            q.strip += GX;
+        }
+    };
+    // strip -> (position nf, column tile j, clip b, padded-clip position p)
+    auto decode = [&](int strip, int& nf, int& j, int& b, int& pp) {
+        nf = (int)((unsigned)strip / 5u);
+        j = strip - nf * 5;
+        b = (int)((float)nf * a.invP);               // nf < 2^24 (checked by the launcher): off by at most one
+        pp = nf - b * a.P;
+        if (pp < 0) { --b; pp += a.P; }
+        else if (pp >= a.P) { ++b; pp -= a.P; }
+    };
 
     if (wave >= 4) {
         // =========================== loader / pool waves ===========================
@@ -101,33 +129,45 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const bool has1 = it1 < TROWS * 25;                                // item ltid + 256  (< 400)
         const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
-        auto issue = [&](long t, C1Regs& R) {
-            const long strip = s_lo + (t / ROW_TILES) * GX;
-            const int rt = (int)(t % ROW_TILES);
-            const long nf = strip / COL_TILES;
-            const int j = (int)(strip - nf * COL_TILES);
-            const int b = (int)(nf / a.P), p = (int)(nf - (long)b * a.P);
+        auto issue = [&](const Pos& q, C1Regs& R) {
+            const int rt = q.rt;
+            int nf, j, b, p;
+            decode(q.strip, nf, j, b, p);
+            // per-lane byte offsets inside a frame (the same for the 5 frames); the frame base is wave-uniform, so
+            // each load is `global_load_dwordx3 v, v_off, s[base]` with no per-load address arithmetic.
+            // UNCONDITIONAL loads from a clamped address: a `cond ? load : 0` select makes hipcc branch
+            // around every load and wait vmcnt(0) after it (10 serial L2 round trips per tile).
+            // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never used.
+            uint32_t off[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = u ? row1 : row0, g = u ? g1 : g0;
+                int ih = rt * 12 + row, px = j * 96 + 4 * g;
+                ih = ih < IH ? ih : IH - 1;
+                px = px < IW ? px : IW - 4;
+                off[u] = (uint32_t)((ih * IW + px) * 3);
+            }
 #pragma unroll
             for (int dt = 0; dt < 5; ++dt) {
                 int f = p + dt - a.pad;
                 f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
-                const uint8_t* fb = a.src + ((long)b * a.T + f) * (IH * IW * 3);
+                const uint8_t* fb = a.src + (size_t)(b * a.T + f) * (size_t)(IH * IW * 3);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int row = u ? row1 : row0, g = u ? g1 : g0;
-                    // UNCONDITIONAL loads from a clamped address: a `cond ? load : 0` select makes hipcc branch
-                    // around every load and wait vmcnt(0) after it (10 serial L2 round trips per tile).
-                    // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never used.
-                    int ih = rt * 12 + row, px = j * 96 + 4 * g;
-                    ih = ih < IH ? ih : IH - 1;
-                    px = px < IW ? px : IW - 4;
-                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb + ((long)ih * IW + px) * 3);
+                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb + off[u]);
                     R.w[u][dt][0] = s[0];
                     R.w[u][dt][1] = s[1];
                     R.w[u][dt][2] = s[2];
                 }
             }
         };
+        // u8 -> fp16 WITHOUT arithmetic: byte n zero-extended to 16 bits IS the fp16 subnormal n * 2^-24, exact for
+        // 0..255, and the MFMA takes fp16 subnormals at full rate.  Every product and partial sum is then the one of
+        // the integer-valued formulation times 2^-24 exactly; the epilogue scale carries the 2^24 (a power of two:
+        // bit-identical results).  One v_perm_b32 places two bytes -> 8 VALU ops per 16-element pixel slot instead
+        // of ~40 (cvt_f32_ubyte + cvt_f16_f32 + pack); the loader waves share their SIMDs with the MFMA waves and
+        // their VALU time is what the tile time was waiting for (JG_CONV1_TL=1).
+        // slot element k = 3*dt + c (dt = frame 0..4, c = channel), k = 15: the bias lane, 2^-24 (= 1.0 * 2^-24).
         auto cvt_write = [&](const C1Regs& R, char* buf) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -135,19 +175,26 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 const int row = u ? row1 : row0, g = u ? g1 : g0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f16 e[16];
+                    uint32_t d[8];
 #pragma unroll
-                    for (int dt = 0; dt < 5; ++dt)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int bi = 3 * q + c;
-                            e[dt * 3 + c] = (f16)(float)((R.w[u][dt][bi >> 2] >> ((bi & 3) * 8)) & 0xffu);
+                    for (int m = 0; m < 8; ++m) {
+                        const int k0 = 2 * m, k1 = 2 * m + 1;
+                        const int b0 = 3 * q + k0 % 3;                               // byte of the 12-byte chunk of frame k0/3
+                        const uint32_t lo = R.w[u][k0 / 3][b0 >> 2];
+                        uint32_t hi = 1u;                                            // k = 15: the constant 0x0001
+                        int hb = 0;
+                        if (k1 < 15) {
+                            const int b1 = 3 * q + k1 % 3;
+                            hi = R.w[u][k1 / 3][b1 >> 2];
+                            hb = b1 & 3;
                         }
-                    e[15] = (f16)1.f;        // bias lane: Wd[slot 0/1][c][15] carry shift/scale as a hi+lo fp16 pair
+                        // v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = 0x00
+                        d[m] = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((4u + hb) << 16) | (uint32_t)(b0 & 3));
+                    }
                     const int x = 4 * g + q;
                     char* dst = buf + row * ROW_PITCH + slot_off(x);
-                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&e[0]);
-                    *reinterpret_cast<uint4*>(dst + 16) = *reinterpret_cast<uint4*>(&e[8]);
+                    *reinterpret_cast<uint4*>(dst) = uint4{d[0], d[1], d[2], d[3]};
+                    *reinterpret_cast<uint4*>(dst + 16) = uint4{d[4], d[5], d[6], d[7]};
                 }
             }
         };
@@ -156,12 +203,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const int pcg = (ltid >> 4) & 7, ppw = ltid & 15;                         // part A: 2 x 8 x 16 threads
         const int prow = __builtin_amdgcn_readfirstlane(ltid >> 7);               // wave-uniform: waves 4,5 / 6,7
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
-        auto pool = [&](long t) {
-            const long strip = s_lo + (t / ROW_TILES) * GX;
-            const int rt = (int)(t % ROW_TILES);
-            const long nf = strip / COL_TILES;
-            const int j = (int)(strip - nf * COL_TILES);
-            const char* cbuf = smem + OFF_CONV + (int)(t & 1) * CONV_BYTES;
+        auto pool = [&](const Pos& q, int t) {
+            const int rt = q.rt;
+            const int nf = (int)((unsigned)q.strip / 5u);
+            const int j = q.strip - nf * 5;
+            const char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
             const char* cin = smem + OFF_CARRY + ((rt & 1) ^ 1) * CARRY_BYTES;
             char* cout = smem + OFF_CARRY + (rt & 1) * CARRY_BYTES;
             auto at = [&](const char* base, int row, int cg, int col) {
@@ -197,33 +243,55 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         };
 
         if (a.dbg & 1) {
-            for (long t = 0; t <= ntl; ++t) __syncthreads();
+            for (int t = 0; t <= ntl; ++t) __syncthreads();
             return;
         }
-        C1Regs RA, RB;
+        int tli = 0;
+        auto mark = [&]() {
+            if (a.tl && blockIdx.x == 0 && wave == 4 && tli < 2000) {
+                const unsigned long long c = wall_clock64();
+                if (lane == 0) a.tl[2048 + tli] = c;
+                ++tli;
+            }
+        };
+        C1Regs R;
+        Pos qi = {s_lo, 0}, qp = {s_lo, 0};       // next tile to issue loads for; next tile to pool
+        int ti = 0;
+        // The frame loads are UNCONDITIONAL (past the end the last tile is simply loaded again): under an
+        // `if (t + 2 < ntl)` the loaded registers become a phi with their old values, hipcc resolves it with
+        // copies right behind the loads, and every tile waits for its own L2/HBM round trip (1.0-1.4 us of
+        // the 3.3 us loader iteration, JG_CONV1_TL=1).
+        auto next_i = [&]() {
+            if (ti + 1 < ntl) {
+                ++ti;
+                advance(qi);
+            }
+        };
         if (ntl > 0) {
-            issue(0, RA);
-            cvt_write(RA, smem);
-            if (1 < ntl) issue(1, RA);
+            issue(qi, R);
+            next_i();
+            cvt_write(R, smem);
+            issue(qi, R);
+            next_i();
         }
-        // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1;
-        // we issue the loads of tile t+2, pool tile t-1 and fill tile buffer (t+1)&1 with tile t+1.
-        long t = 0;
-        while (t < ntl) {
+        // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1.  We
+        //   (1) fill tile buffer (t+1)&1 from the registers loaded ONE WHOLE ITERATION ago (the vmcnt wait in
+        //       front of it is free: hipcc waits vmcnt(0) whenever loads and stores are both pending),
+        //   (2) reload the same registers with tile t+2,
+        //   (3) pool tile t-1 (its stores go last: their acknowledgement is what the next vmcnt(0) sees).
+        for (int t = 0; t < ntl; ++t) {
+            mark();
             __syncthreads();
-            if (t + 2 < ntl && !(a.dbg & 16)) issue(t + 2, RB);
-            if (t > 0 && !(a.dbg & 4)) pool(t - 1);
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RA, smem + (int)((t + 1) & 1) * TILE_BYTES);
-            ++t;
-            if (t >= ntl) break;
-            __syncthreads();
-            if (t + 2 < ntl && !(a.dbg & 16)) issue(t + 2, RA);
-            if (!(a.dbg & 4)) pool(t - 1);
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RB, smem + (int)((t + 1) & 1) * TILE_BYTES);
-            ++t;
+            mark();
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(R, smem + ((t + 1) & 1) * TILE_BYTES);
+            mark();
+            issue(qi, R);
+            next_i();
+            mark();
+            if (t > 0 && !(a.dbg & 4)) { pool(qp, t - 1); advance(qp); }
         }
         __syncthreads();                       // the MFMA waves have finished the last tile
-        if (ntl > 0) pool(ntl - 1);
+        if (ntl > 0 && !(a.dbg & 4)) pool(qp, ntl - 1);
         return;
     }
 
@@ -238,11 +306,21 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     //   (3*mb+kh)*ROW_PITCH + 32*x + 16*(x/3) + 16*h = [112*r + 16*h] + [kh*ROW_PITCH + 32*kw + 16*(kw/3)]
     const int lbase = 112 * r + 16 * h;
     constexpr int DEPTH = 6;                             // patch fragments in flight per wave
-    for (long t = 0; t < ntl; ++t) {
+    int tli = 0;
+    auto mark = [&]() {
+        if (a.tl && blockIdx.x == 0 && wave == 0 && tli < 2000) {
+            const unsigned long long c = wall_clock64();
+            if (lane == 0) a.tl[tli] = c;
+            ++tli;
+        }
+    };
+    for (int t = 0; t < ntl; ++t) {
+        mark();
         __syncthreads();
+        mark();
         if (a.dbg & 2) continue;
-        const char* cur = smem + (int)(t & 1) * TILE_BYTES;
-        char* cbuf = smem + OFF_CONV + (int)(t & 1) * CONV_BYTES;
+        const char* cur = smem + (t & 1) * TILE_BYTES;
+        char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
         // The two blocks of a tile form ONE stream of 98 (block, slot) steps with DEPTH fragments in
         // flight, so block 1's first fragments are already loading while block 0's epilogue runs.
         const char* base = cur + 3 * mb0 * ROW_PITCH + lbase;
@@ -316,13 +394,36 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     }
     Conv1Args a;
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
-    a.Wd = Wd; a.scale = scale; a.out = out_pooled; a.edge = edge;
-    a.nstrips = (long)nclip * a.P * COL_TILES;
+    a.Wd = Wd; a.scale = scale * 16777216.0f; a.out = out_pooled; a.edge = edge;      // 2^24: the loaders feed n * 2^-24 (fp16 subnormals)
+    if ((long)nclip * a.P >= (1L << 24)) return hipErrorInvalidValue;     // decode() splits positions with a float reciprocal
+    a.nstrips = nclip * a.P * COL_TILES;
+    a.invP = 1.0f / (float)a.P;
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;
+    static unsigned long long* tl = nullptr;
+    static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
+    if (want_tl && !tl && hipHostMalloc(&tl, 4096 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) tl = nullptr;
+    a.tl = tl;
+    if (tl) {
+        (void)hipStreamSynchronize(s);
+        std::memset(tl, 0, 4096 * sizeof(unsigned long long));
+    }
     if (a.nstrips <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(a.nstrips < num_cu ? a.nstrips : num_cu);
     hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    if (tl) {
+        (void)hipStreamSynchronize(s);
+        // MFMA wave 0: per tile [arrive, pass]; loader wave 4: per tile [arrive, pass, loads issued, pooled]
+        double wait = 0, work = 0; int n = 0;
+        for (int i = 0; i + 2 < 2000 && tl[i + 2]; i += 2, ++n) { wait += (tl[i + 1] - tl[i]) * 0.01; work += (tl[i + 2] - tl[i + 1]) * 0.01; }
+        if (n) std::fprintf(stderr, "[conv1 timeline] MFMA wave: %d tiles, barrier wait %.2f us, MFMA+epilogue %.2f us per tile\n", n, wait / n, work / n);
+        double w2 = 0, is = 0, po = 0, cv = 0; n = 0;
+        const unsigned long long* q = tl + 2048;
+        for (int i = 0; i + 4 < 2000 && q[i + 4]; i += 4, ++n) {
+            w2 += (q[i + 1] - q[i]) * 0.01; is += (q[i + 2] - q[i + 1]) * 0.01; po += (q[i + 3] - q[i + 2]) * 0.01; cv += (q[i + 4] - q[i + 3]) * 0.01;
+        }
+        if (n) std::fprintf(stderr, "[conv1 timeline] loader wave: %d tiles, barrier wait %.2f us, convert+fill %.2f us, issue loads %.2f us, pool %.2f us per tile\n", n, w2 / n, is / n, po / n, cv / n);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long n = (long)nclip * a.P * PH * 4 * 8;
