@@ -695,12 +695,12 @@ void gemm_set_timeline(bool on) {
     if (on && !g_tl) {
         if (hipHostMalloc(&g_tl, 1024 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) g_tl = nullptr;
     } else if (!on && g_tl) {
-        hipHostFree(g_tl);
+        (void)hipHostFree(g_tl);
         g_tl = nullptr;
     }
 }
 static void dump_timeline(hipStream_t s, const char* what) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     for (int b = 0; b < 2; ++b) {
         const unsigned long long* t = g_tl + b * 512;
         std::fprintf(stderr, "[gemm timeline %s wg %s] (100 MHz ticks -> us)\n", what, b ? "last" : "0");
@@ -715,7 +715,7 @@ static const f16* zero_page() {
     static f16* z = nullptr;
     if (!z) {
         if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        hipMemset(z, 0, 256);
+        (void)hipMemset(z, 0, 256);
     }
     return z;
 }
@@ -744,7 +744,7 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
     const int tiles = mt * nt;
     const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
     if (g_tl) {
-        hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s);
         std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
     }
     hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (g_stagger << 8), g_tl);
@@ -774,7 +774,7 @@ static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
     const int tiles = (a.M + 127) / 128;
     const int grid = tiles < num_cu ? tiles : num_cu;
     if (g_tl) {
-        hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s);
         std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
     }
     hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, g_counted | (g_stagger << 8), g_tl);

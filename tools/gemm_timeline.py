@@ -9,7 +9,7 @@ from jegal_amd._lib import Engine
 eng = Engine(0)
 for o in sys.argv[1:]:
     k, v = o.split('='); eng.set_option(k, int(v))
-M = 100800
+M = int(os.environ.get("GEMM_M", 100800))
 for (N, K, mode, name) in [(1536, 512, 0, "qkv"), (512, 512, 2, "out_proj+res"), (512, 512, 10, "out_proj+res+LN"), (512, 2048, 10, "linear2+res+LN")]:
     eng.debug_gemm(M, N, K, mode, 2)       # warm
     eng.set_option("gemm_timeline", 1)
