@@ -32,9 +32,11 @@ CONV1_GFLOP_PER_CLIP = 154 * 13904 * 64 * 735 * 2 / 1e9
 TOTAL_GFLOP_PER_CLIP = 464.9       # SURVEY 8d total, v-only
 LINEAR_GFLOP_PER_CLIP = 131.1      # GestSync transformer + ff_vid (124.7) + JEGAL gesture + align (6.4)
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 (MI355X_MICROARCH.md)
-# HBM traffic of one conv1_direct_kernel launch (32 clips) from rocprofv3 PMC passes (profiles/r1b_pmc_hbm_traffic.csv
-# + profiles/README.md): FETCH_SIZE 1.39e6 KB (doubled: gfx950 counts 64 B per 128-B request), WRITE_SIZE 2.17e6 KB.
-CONV1_TRAFFIC_BYTES_PER_32CLIPS = (2 * 1.39e6 + 2.17e6) * 1024
+# HBM traffic of one conv1_direct_kernel launch (32 clips) from separate rocprofv3 --pmc passes (profiles/r1d_pmc_hbm_traffic.csv
+# + profiles/README.md): FETCH_SIZE 2.2e6 KB, WRITE_SIZE 2.17e6 KB.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+# gfx950 (128-B requests tallied at 64 B); that rule is calibrated for 16-B/lane streaming reads, the frame loads here are
+# 12 B/lane, so the doubled figure is an upper bound (Infinity-Cache hits are counted as well).
+CONV1_TRAFFIC_BYTES_PER_32CLIPS = (2 * 2.2e6 + 2.17e6) * 1024
 
 
 def cpu_baseline(clip_u8, n_windows=150):
@@ -145,7 +147,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU, 154 distinct positions/clip)", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": CONV1_TRAFFIC_BYTES_PER_32CLIPS * clips_per_launch / 32.0,
-                         "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1b_pmc_hbm_traffic.csv (not re-measured in this run); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
+                         "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1d_pmc_hbm_traffic.csv (separate --pmc passes, not re-measured in this run; upper bound, includes Infinity-Cache hits); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n,
                          "whole_path_frac": value / world * TOTAL_GFLOP_PER_CLIP / 1e3 / MFMA_PEAK_TFLOPS},
             # second-largest consumer: all Linear-layer GEMM launches of a step taken together (algorithmic FLOPs only:

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const int ph = 2 * rt - 1 + prow;
             const int pw = 16 * j + ppw;
             if (ph >= 0 && pw < PW)
-                *reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8) = m;
+                __builtin_nontemporal_store(m, reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8));   // streamed: keep the frames in L2
             if (ph >= 0 && j > 0 && ppw == 0) {     // export conv column 0 (vertically pooled) for strip j-1's last pooled column
                 f16x8 e;
                 if (prow == 0) e = max8(at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
