@@ -153,9 +153,141 @@ __global__ __launch_bounds__(256) void attn_kernel(const f16* __restrict__ qkv, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for the GestSync layers: S <= 32 keys, dk = 64, no mask.  One wave per (sequence, head) pair,
+// four independent waves per workgroup (no workgroup barrier).
+//   S^T = K Q^T   (keys x queries, 4 x v_mfma_f32_32x32x16_f16 over d): K rows and Q rows are the A and B
+//                 operands straight from global memory (lane = row, 16 B = 8 consecutive d);
+//   softmax over the keys of a query = over the 16 accumulator registers of a lane and its partner lane+32;
+//   O^T = V^T P^T (d x queries, 2 row blocks x 2 k-steps): P^T is ALREADY in B-operand order in the S^T
+//                 accumulators (lane = query; the k-step's 8 keys of lane half h are 4h+{0..3}+16s and
+//                 4h+{0..3}+16s+8), V^T comes from a transposed copy of the head's V rows in LDS, read in
+//                 the same key order.  P is split into fp16 hi+lo (two MFMAs per block): the probabilities
+//                 keep fp32 accuracy, as in the VALU kernel, and the matrix pipe has nothing else to do.
+//   The output tile is transposed back through LDS so the stores are whole 128-B rows.
+// Rows >= S are clamped on load (finite values), masked to -inf as keys and never stored as queries.
+__global__ __launch_bounds__(256) void attn_mfma_s32_kernel(const f16* __restrict__ qkv, int npairs, int S, int H, f16* __restrict__ out) {
+    constexpr int DK = 64, VT_PITCH = 72, O_PITCH = 144;
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * VT_PITCH + 32 * O_PITCH)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= npairs) return;
+    char* sVt = smem + wave * (64 * VT_PITCH + 32 * O_PITCH);
+    char* sO = sVt + 64 * VT_PITCH;
+    const int b = pair / H, head = pair - b * H;
+    const int D = H * DK;
+    const long ld = 3L * D;
+    const f16* base = qkv + (long)b * S * ld + head * DK;
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int rowc = r31 < S ? r31 : S - 1;
+
+    // ---- operand loads (issued together; V goes through LDS)
+    f16x8 kA[4], qB[4];
+    const f16* qrow = base + (long)rowc * ld + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qB[s] = *reinterpret_cast<const f16x8*>(qrow + 16 * s);
+        kA[s] = *reinterpret_cast<const f16x8*>(qrow + D + 16 * s);
+    }
+    f16x8 vv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+        const int rc = row < S ? row : S - 1;
+        vv[r] = *reinterpret_cast<const f16x8*>(base + (long)rc * ld + 2 * D + part * 8);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(sVt + (part * 8 + e) * VT_PITCH + row * 2) = vv[r][e];
+    }
+
+    // ---- S^T = K Q^T
+    f32x16 sc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kA[s], qB[s], sc, 0, 0, 0);
+
+    // ---- softmax over keys: register i <-> key (i&3) + 8(i>>2) + 4*hh
+    const float scale = 0.125f;                       // 1/sqrt(64)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        sc[i] = key < S ? sc[i] * scale : -INFINITY;
+        mx = fmaxf(mx, sc[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sc[i] = __expf(sc[i] - mx);                   // exp(-inf) = 0 for the masked keys
+        sum += sc[i];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f16x8 pH[2], pL[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float pv = sc[4 * (2 * s + (j >> 2)) + (j & 3)] * inv;
+            const f16 hi = (f16)pv;
+            pH[s][j] = hi;
+            pL[s][j] = (f16)(pv - (float)hi);
+        }
+
+    // ---- O^T = V^T P^T
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x16 o[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char* vp = sVt + (r31 + 32 * blk) * VT_PITCH + (16 * s + 4 * hh) * 2;
+            const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
+            const f16x8 vA = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pH[s], o[blk], 0, 0, 0);
+            o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pL[s], o[blk], 0, 0, 0);
+        }
+    }
+    // ---- O^T (register i <-> d = (i&3) + 8(i>>2) + 4*hh + 32*blk, lane <-> query) -> [query][d] fp16 in LDS -> rows
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f16x4 hv = {(f16)o[blk][4 * g], (f16)o[blk][4 * g + 1], (f16)o[blk][4 * g + 2], (f16)o[blk][4 * g + 3]};
+            *reinterpret_cast<f16x4*>(sO + r31 * O_PITCH + (32 * blk + 8 * g + 4 * hh) * 2) = hv;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f16* obase = out + (long)b * S * D + head * DK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+        if (row < S) *reinterpret_cast<f16x8*>(obase + (long)row * D + part * 8) = *reinterpret_cast<const f16x8*>(sO + row * O_PITCH + part * 16);
+    }
+}
+
+static bool g_attn_mfma = true;
+void attention_set_mfma(bool on) { g_attn_mfma = on; }
+
 hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, hipStream_t s) {
     if (B <= 0 || S <= 0) return hipSuccess;
     const long npairs = (long)B * H;
+    if (g_attn_mfma && S <= 32 && dk == 64 && !keymask && npairs < (1L << 31)) {
+        hipLaunchKernelGGL(attn_mfma_s32_kernel, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out);
+        return hipGetLastError();
+    }
     dim3 grid, block;
     int G = 1;
     if (S <= 32) {

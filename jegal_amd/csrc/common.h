@@ -55,6 +55,7 @@ void gemm_set_ring_cfg(int c);
 void gemm_set_persistent(bool on);
 void gemm_set_counted(int on);
 void gemm_set_stagger(int ticks);
+void attention_set_mfma(bool on);
 void gemm_set_timeline(bool on);
 void gemm_set_big_tile(bool on);
 void gemm_set_small_tile(bool on);
