@@ -94,3 +94,83 @@ def gestsync_feats_to_npy(gestsync, clips, out_paths, rank=None, nshard=None):
         np.save(out_paths[i], feats.cpu().numpy())
         done += 1
     return done
+
+
+class GestureStreamer:
+    """Streams host-resident clips through ``jg_extract_gesture`` with the uploads hidden behind the compute.
+
+    A 32-clip batch of uint8 crops is 1.87 GB; at PCIe Gen5 rates its upload takes longer than the 17 ms
+    the GPU needs for it, so a serving / dataset-extraction loop must keep the copy engine busy all the
+    time: two pinned host buffers + two device buffers, batch k+1 is packed and copied (copy stream) while
+    batch k runs (compute stream), batch k-1's embeddings go back on the copy stream.  torch is plumbing
+    only (pinned memory, streams, events); the compute is one library call per batch.
+
+    ``run(clips)``: ``clips`` iterates over (T,270,480,3) uint8 numpy arrays of one common T; yields
+    ``(first_clip_index, embeddings (n,T,512) float32 numpy)`` per batch, in order.
+    (The reference's loop does this synchronously per clip: inference_embs.py:476-522,629-637.)
+    """
+
+    def __init__(self, engine, batch=32, frames=150):
+        self.eng, self.batch, self.T = engine, int(batch), int(frames)
+        dev = engine.device
+        shape = (self.batch, self.T, 270, 480, 3)
+        self.h_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.d_in = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.d_out = [torch.empty((self.batch, self.T, 512), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.h_out = [torch.empty((self.batch, self.T, 512), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.copy = torch.cuda.Stream(dev)          # H2D
+        self.down = torch.cuda.Stream(dev)          # D2H: on its own stream, or upload k+1 would queue behind `wait computed k`
+        self.compute = torch.cuda.Stream(dev)
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.computed = [torch.cuda.Event() for _ in range(2)]
+        self.downloaded = [torch.cuda.Event() for _ in range(2)]
+
+    def _pack(self, it, slot):
+        """Fill pinned buffer `slot` from the iterator; returns the number of clips packed."""
+        n = 0
+        dst = self.h_in[slot].numpy()
+        for clip in it:
+            clip = np.asarray(clip)
+            if clip.shape != (self.T, 270, 480, 3) or clip.dtype != np.uint8:
+                raise ValueError(f"clip must be uint8 ({self.T},270,480,3), got {clip.dtype} {clip.shape}")
+            dst[n] = clip
+            n += 1
+            if n == self.batch:
+                break
+        return n
+
+    def run(self, clips):
+        """clips: iterable of (T,270,480,3) uint8 arrays (copied into the pinned staging buffers here)."""
+        it = iter(clips)
+        return self.run_filled(lambda buf, k: self._pack(it, k & 1))
+
+    def run_filled(self, fill):
+        """fill(pinned_uint8_array (batch,T,270,480,3), batch_index) -> number of clips written (0 = end).
+        For producers (decoders) that can write their crops straight into the pinned buffer."""
+        pending = []                      # (slot, first index, n) of batches whose embeddings are not yet returned
+        first, k = 0, 0
+        n = fill(self.h_in[0].numpy(), 0)
+        while n > 0 or pending:
+            slot = k & 1
+            if n > 0:
+                with torch.cuda.stream(self.copy):
+                    self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
+                    self.uploaded[slot].record(self.copy)
+                with torch.cuda.stream(self.compute):
+                    self.compute.wait_event(self.uploaded[slot])
+                    self.eng.extract_gesture(self.d_in[slot][:n], self.d_out[slot][:n])
+                    self.computed[slot].record(self.compute)
+                with torch.cuda.stream(self.down):
+                    self.down.wait_event(self.computed[slot])
+                    self.h_out[slot][:n].copy_(self.d_out[slot][:n], non_blocking=True)
+                    self.downloaded[slot].record(self.down)
+                pending.append((slot, first, n))
+                first += n
+            # pack the next batch on the host while the GPU works on this one; its pinned buffer and its
+            # device buffers were last used by batch k-1, whose results must be handed out first
+            if len(pending) == 2 or n == 0:
+                s0, f0, n0 = pending.pop(0)
+                self.downloaded[s0].synchronize()
+                yield f0, self.h_out[s0][:n0].numpy().copy()
+            k += 1
+            n = fill(self.h_in[k & 1].numpy(), k) if n > 0 else 0

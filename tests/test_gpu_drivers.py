@@ -81,3 +81,34 @@ def test_drivers_roundtrip(tmp_path):
     wbs = [eval(r["word_boundaries"]) for r in rows]
     tg = [wb.index(eval(r["target_word_boundary"])) for wb, r in zip(wbs, rows)]
     assert acc == pytest.approx(O.spotting_accuracy([f["gesture_emb"] for f in feats], [f["content_emb"] for f in feats], wbs, tg))
+
+
+def test_gesture_streamer_matches_resident_path():
+    """Pinned double-buffered streaming (ragged last batch, both producer interfaces) returns exactly what
+    the HBM-resident call returns, in order."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.extract import GestureStreamer
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    eng = Engine(0)
+    GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    T, n = 8, 7
+    clips = synth.synth_frames(77, n, T)
+    # same batching as the streamer: the GEMM tile configuration (and with it the fp32 summation order) depends on M
+    ref = np.concatenate([eng.extract_gesture(torch.from_numpy(clips[i:i + 3]).cuda()).cpu().numpy() for i in range(0, n, 3)])
+    st = GestureStreamer(eng, batch=3, frames=T)
+    got = list(st.run(iter(clips)))
+    assert [f for f, _ in got] == [0, 3, 6] and [e.shape[0] for _, e in got] == [3, 3, 1]
+    np.testing.assert_array_equal(np.concatenate([e for _, e in got]), ref)
+
+    def fill(buf, k):                       # a producer writing straight into the pinned buffer
+        lo, hi = 3 * k, min(n, 3 * k + 3)
+        if lo >= n:
+            return 0
+        buf[:hi - lo] = clips[lo:hi]
+        return hi - lo
+    got2 = list(st.run_filled(fill))
+    np.testing.assert_array_equal(np.concatenate([e for _, e in got2]), ref)
+    with pytest.raises(ValueError):
+        list(st.run([clips[0][:4]]))
