@@ -79,6 +79,14 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
  * -> out (N,1024,21) fp32, optional out_conv (N,512,21) fp32 (NULL to skip). */
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv);
 
+/* Face-mask + resize pre-step, load_rgb_masked_frames (inference_embs.py:235-276) without the /255 and the edge pad
+ * (those live in jg_gestsync_clip): src (T,H,W,3) uint8 device frames, mask_y (T) int32 DEVICE array -- per frame the
+ * last source row blanked by cv2.rectangle(img,(0,0),(W,y2+15),0,-1) (face found: mask, then resize), or -1 when
+ * mediapipe found no face (resize, then rows 0..110 of the result blanked) -> dst (T,270,480,3) uint8, ready for
+ * jg_gestsync_clip.  cv2.resize(INTER_LINEAR, 8-bit) restated from OpenCV's generic fixed-point path; parity unpinned
+ * (cv2 absent).  The keypoints themselves stay on the host (mediapipe). */
+int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const int32_t* mask_y, uint8_t* dst);
+
 /* ---- JEGAL (models/jegal.py) ---------------------------------------------------------------- */
 /* forward_gestures (jegal.py:78-92) [+ proj_op_align_gesture, jegal.py:381 when align != 0]:
  * feats (B,T,1024) fp32, mask (B,T) fp32 (1 valid / 0 pad) or NULL -> out (B,T,512) fp32. */

@@ -38,6 +38,7 @@ _SIGS = {
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
     "jg_logmel": [_P, _P, _I, _I, _P, _P],
+    "jg_mask_resize": [_P, _P, _I, _I, _I, _P, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
     "jg_fuse_content": [_P, _P, _I, _P],
@@ -268,6 +269,21 @@ class Engine:
             raise ValueError("mel must have 80 bands")
         out = torch.empty((B, self.audio_len(Tm), 256), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_jegal_audio(self.h, _ptr(mel), B, Tm, _ptr(out)))
+        return out
+
+    def mask_resize(self, frames_u8, mask_y):
+        """load_rgb_masked_frames (inference_embs.py:235-276) minus /255 and the edge pad: (T,H,W,3) uint8 source frames,
+        mask_y (T,) int (last blanked source row = y2+15, or -1 for "no face") -> (T,270,480,3) uint8 masked crops."""
+        self._bind_stream()
+        frames_u8 = frames_u8.to(self.device).contiguous()
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+            raise ValueError("frames must be uint8 (T,H,W,3)")
+        T, H, W, _ = frames_u8.shape
+        my = torch.as_tensor(mask_y, dtype=torch.int32).to(self.device).contiguous()
+        if my.numel() != T:
+            raise ValueError("mask_y needs one entry per frame")
+        out = torch.empty((T, 270, 480, 3), dtype=torch.uint8, device=self.device)
+        self._ck(self.lib.jg_mask_resize(self.h, _ptr(frames_u8), T, H, W, _ptr(my), _ptr(out)))
         return out
 
     def logmel(self, wav, mel_basis):

@@ -963,6 +963,12 @@ int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out) {
     return jegal_audio_impl(h, mel, B, Tm, out);
 }
 
+int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const int32_t* mask_y, uint8_t* dst) {
+    if (!h) return JG_ERR_ARG;
+    if (!src || !mask_y || !dst || T <= 0 || H <= 0 || W <= 0) JG_FAIL(h, JG_ERR_ARG, "bad mask_resize arguments");
+    return timed(h, JG_ST_MISC, [&] { return launch_mask_resize(src, T, H, W, mask_y, dst, h->stream); });
+}
+
 int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out) {
     if (!h) return JG_ERR_ARG;
     if (!wav || !mel_basis || !out || B <= 0 || n_samples < 160) JG_FAIL(h, JG_ERR_ARG, "bad logmel arguments");

@@ -440,3 +440,64 @@ hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* me
     hipLaunchKernelGGL(logmel_kernel, dim3(n_frames, B), dim3(256), 0, s, wav, n_samples, n_frames, mel_basis, out);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Face-mask + resize pre-step (inference_embs.py:235-276): per frame
+//   face found : cv2.rectangle(img,(0,0),(W,y2+15),0,-1) at SOURCE resolution, then cv2.resize(img,(480,270))
+//   face None  : cv2.resize first, then cv2.rectangle(img,(0,0),(480,110),0,-1)
+// as ONE uint8 -> uint8 kernel (mask_y[f] >= 0: last blanked source row; -1: the face-None case).
+// cv2.resize default = INTER_LINEAR on 8-bit: restated from OpenCV's generic fixed-point path
+// (modules/imgproc/src/resize.cpp: coefficients cvRound(w*2048) as short, horizontal pass in int,
+// vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  cv2 is not installed here and the
+// pip wheels may dispatch to IPP: PARITY UNPINNED (oracle/jegal_oracle.py:mask_resize_frames is the same
+// restatement in numpy).
+__global__ void mask_resize_kernel(const uint8_t* __restrict__ src, int T, int H, int W, const int* __restrict__ mask_y,
+                                   uint8_t* __restrict__ dst) {
+    constexpr int OH = 270, OW = 480;
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)T * OH * OW) return;
+    const int dx = (int)(idx % OW);
+    const int dy = (int)((idx / OW) % OH);
+    const int f = (int)(idx / ((long)OW * OH));
+    const int my = mask_y[f];
+    uint8_t* o = dst + idx * 3;
+    if (my < 0 && dy <= 110) {                 // face None: rows 0..110 of the RESIZED frame (rectangle corners inclusive)
+        o[0] = o[1] = o[2] = 0;
+        return;
+    }
+    const double scale_x = (double)W / OW, scale_y = (double)H / OH;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx + 1 >= W) { fx = 0.f; sx = W - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    auto sat_short = [](float v) -> int {
+        int r = __float2int_rn(v);
+        return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+    };
+    const int a0 = sat_short((1.f - fx) * 2048.f), a1 = sat_short(fx * 2048.f);
+    const int b0 = sat_short((1.f - fy) * 2048.f), b1 = sat_short(fy * 2048.f);
+    const int y0 = sy < 0 ? 0 : (sy < H ? sy : H - 1);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < H ? sy + 1 : H - 1);
+    const int x1 = sx + 1 < W ? sx + 1 : W - 1;
+    const uint8_t* fr = src + (long)f * H * W * 3;
+    const bool z0 = my >= 0 && y0 <= my, z1 = my >= 0 && y1 <= my;       // blanked source rows
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int p00 = z0 ? 0 : fr[((long)y0 * W + sx) * 3 + c], p01 = z0 ? 0 : fr[((long)y0 * W + x1) * 3 + c];
+        const int p10 = z1 ? 0 : fr[((long)y1 * W + sx) * 3 + c], p11 = z1 ? 0 : fr[((long)y1 * W + x1) * 3 + c];
+        const int S0 = p00 * a0 + p01 * a1, S1 = p10 * a0 + p11 * a1;
+        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s) {
+    const long n = (long)T * 270 * 480;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, T, H, W, mask_y_dev, dst);
+    return hipGetLastError();
+}

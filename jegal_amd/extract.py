@@ -174,3 +174,29 @@ class GestureStreamer:
                 yield f0, self.h_out[s0][:n0].numpy().copy()
             k += 1
             n = fill(self.h_in[k & 1].numpy(), k) if n > 0 else 0
+
+
+# mediapipe face-mesh indices of the face oval (inference_embs.py:248-250)
+FACE_OVAL_IDX = (10, 21, 54, 58, 67, 93, 103, 109, 127, 132, 136, 148, 149, 150, 152, 162, 172, 176, 234, 251, 284, 288,
+                 297, 323, 332, 338, 356, 361, 365, 377, 378, 379, 389, 397, 400, 454)
+
+
+def load_rgb_masked_frames(engine, input_frames, kp_dict):
+    """Counterpart of inference_embs.py:235-286 (`load_rgb_masked_frames`) with the pixel work on the GPU.
+
+    input_frames: (T,H,W,3) uint8 array/tensor (or list of equally sized frames); kp_dict = {"kps": per-frame dicts with
+    "face" = list of {"x","y"} landmarks (normalised) or None, "resolution": (H, W)} as written by the reference's
+    mediapipe step.  Returns the masked (T,270,480,3) uint8 crops on the device; the /255 and the +-12 frame edge
+    padding of :279-283 are part of `jg_gestsync_clip`.  The per-frame mask row y2+15 (:266-270) is computed here on
+    the host exactly as the reference does (int() truncation of landmark*resolution, max over the oval)."""
+    kps, res = kp_dict["kps"], kp_dict["resolution"]
+    mask_y = []
+    for fk in kps:
+        face = fk["face"]
+        if face is None:
+            mask_y.append(-1)
+        else:
+            ys = [int(face[i]["y"] * res[0]) for i in range(len(face)) if i in FACE_OVAL_IDX]
+            mask_y.append(max(ys) + 15)
+    frames = torch.as_tensor(np.asarray(input_frames))
+    return engine.mask_resize(frames, mask_y)

@@ -411,3 +411,58 @@ def load_text(text_path, fps=25):
                 text += " "
             wbs.append([word, round(float(parts[1]) * fps), round(float(parts[2]) * fps)])
     return [text], [wbs]
+
+
+# ------------------------------------------------------------------------------------------------
+# Face-mask + resize pre-step (inference_embs.py:235-276), SURVEY 8f-4.  PARITY UNPINNED: cv2 is not
+# installed in this image; cv2.resize(img, (480, 270)) (INTER_LINEAR, 8-bit) is restated from OpenCV's
+# published generic fixed-point algorithm (modules/imgproc/src/resize.cpp), the pip wheels may use IPP.
+def _cv_linear_coeffs(dsize, ssize):
+    """per destination index: source index (clamped as OpenCV does for x) and the two short coefficients"""
+    scale = float(ssize) / float(dsize)
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    return s, f
+
+
+def _sat_short(x):
+    return np.clip(np.rint(x.astype(np.float32)), -32768, 32767).astype(np.int64)      # cvRound: half to even
+
+
+def cv_resize_linear_u8(img, width=480, height=270):
+    """img (H,W,C) uint8 -> (height,width,C) uint8."""
+    H, W = img.shape[:2]
+    sx, fx = _cv_linear_coeffs(width, W)
+    lo = sx < 0
+    fx[lo] = 0.0; sx[lo] = 0
+    hi = sx + 1 >= W
+    fx[hi] = 0.0; sx[hi] = W - 1
+    a0 = _sat_short((np.float32(1.0) - fx) * np.float32(2048.0)); a1 = _sat_short(fx * np.float32(2048.0))
+    x1 = np.minimum(sx + 1, W - 1)
+    sy, fy = _cv_linear_coeffs(height, H)
+    b0 = _sat_short((np.float32(1.0) - fy) * np.float32(2048.0)); b1 = _sat_short(fy * np.float32(2048.0))
+    y0 = np.clip(sy, 0, H - 1); y1 = np.clip(sy + 1, 0, H - 1)
+    src = img.astype(np.int64)
+    rows = src[:, sx] * a0[None, :, None] + src[:, x1] * a1[None, :, None]              # horizontal pass (H, width, C)
+    v = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def mask_resize_frames(frames_u8, mask_y, width=480, height=270):
+    """inference_embs.py:255-276 per frame: face found (mask_y >= 0): blank source rows 0..mask_y (cv2.rectangle with
+    inclusive corners), then resize; face None (mask_y < 0): resize, then blank rows 0..110.  -> (T,270,480,3) uint8
+    (the /255 and the +-12 edge pad of :279-283 are applied downstream)."""
+    out = np.empty((len(frames_u8), height, width, 3), dtype=np.uint8)
+    for i, img in enumerate(frames_u8):
+        img = np.array(img, dtype=np.uint8)
+        my = int(mask_y[i])
+        if my < 0:
+            r = cv_resize_linear_u8(img, width, height)
+            r[:111] = 0
+        else:
+            img[:min(my, img.shape[0] - 1) + 1] = 0
+            r = cv_resize_linear_u8(img, width, height)
+        out[i] = r
+    return out

@@ -112,3 +112,27 @@ def test_gesture_streamer_matches_resident_path():
     np.testing.assert_array_equal(np.concatenate([e for _, e in got2]), ref)
     with pytest.raises(ValueError):
         list(st.run([clips[0][:4]]))
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (360, 640), (720, 1280), (301, 533), (135, 240)])
+def test_mask_resize_matches_oracle(H, W):
+    """face-mask + cv2-style bilinear resize kernel == the numpy restatement, bit for bit
+    (up- and down-scaling, identity size, odd sizes; face / no-face / mask-beyond-frame rows)."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.extract import load_rgb_masked_frames, FACE_OVAL_IDX
+    eng = Engine(0)
+    rng = np.random.default_rng(H * 1000 + W)
+    T = 4
+    frames = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+    mask_y = [-1, H // 3, 0, H + 50]
+    got = eng.mask_resize(torch.from_numpy(frames), mask_y).cpu().numpy()
+    ref = O.mask_resize_frames(frames, mask_y)
+    np.testing.assert_array_equal(got, ref)
+    assert got[0, :111].max() == 0 and got[3].max() == 0
+    # through the reference-shaped entry point: landmarks -> y2 + 15
+    face = [{"x": 0.5, "y": 0.0} for _ in range(468)]
+    face[FACE_OVAL_IDX[3]] = {"x": 0.5, "y": 0.25}
+    kp = {"kps": [{"face": None}, {"face": face}, {"face": face}, {"face": None}], "resolution": (H, W)}
+    got2 = load_rgb_masked_frames(eng, frames, kp).cpu().numpy()
+    my = int(0.25 * H) + 15
+    np.testing.assert_array_equal(got2, O.mask_resize_frames(frames, [-1, my, my, -1]))

@@ -139,3 +139,17 @@ def test_load_text(golden_dir, tmp_path):
         text, wbs = O.load_text(str(p))
         assert text == r["text"]
         assert wbs == r["word_boundaries"]
+
+
+def test_cv_resize_restatement_properties():
+    """The cv2.resize(INTER_LINEAR, uint8) restatement (parity unpinned: cv2 absent) at least has the properties the
+    published algorithm guarantees: identity at equal size, constants preserved, exact 2x box average within rounding."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+    assert np.array_equal(O.cv_resize_linear_u8(img), img)
+    assert np.all(O.cv_resize_linear_u8(np.full((720, 1280, 3), 137, np.uint8)) == 137)
+    big = rng.integers(0, 256, (540, 960, 3), dtype=np.uint8)
+    box = big.astype(np.float32).reshape(270, 2, 480, 2, 3).mean((1, 3))
+    assert np.abs(O.cv_resize_linear_u8(big).astype(np.float32) - box).max() <= 0.5
+    out = O.mask_resize_frames(rng.integers(0, 256, (2, 300, 500, 3), dtype=np.uint8), [-1, 100])
+    assert out.shape == (2, 270, 480, 3) and out[0, :111].max() == 0 and out[0, 111].max() > 0 and out[1, :80].max() == 0
