@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             if (!LNF) stage(0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
-        mark();     // 2: next tile's first DMA issued
+        if (!LNF) mark();     // 2: next tile's first DMA issued (LNF: statistics done, see below)
 
         if constexpr (LNF) {
             // ---- fused residual + LayerNorm epilogue (gestsync.py:20: LN(x + sublayer(x)), eps 1e-5).
@@ -510,6 +510,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 lw[i] = *reinterpret_cast<const f32x4*>(a.ln_w + nbase + i * 16);
                 lb[i] = *reinterpret_cast<const f32x4*>(a.ln_b + nbase + i * 16);
             }
+            mark();     // 2 (LNF): row statistics done, the store / reload phase starts
             float* o32 = const_cast<float*>(res_tile(a.out32, cm0));
             const float* rnext = res_tile(a.res, m0);                      // m0 is already the next tile's
             f16* orow = a.out16 + (long)(cm0 + (lane >> 3)) * a.ldc + cn0 + wn * 64 + (lane & 7) * 8;
