@@ -813,6 +813,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!h || !name) return JG_ERR_ARG;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_timeline")) { gemm_set_timeline(value != 0); return JG_OK; }
+    if (!std::strcmp(name, "conv1_zero_skip")) { conv1_set_zero_skip(value != 0); return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { attention_set_mfma(value != 0); return JG_OK; }
     if (!std::strcmp(name, "gemm_stagger")) { gemm_set_stagger(value); return JG_OK; }
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }

@@ -56,6 +56,7 @@ void gemm_set_persistent(bool on);
 void gemm_set_counted(int on);
 void gemm_set_stagger(int ticks);
 void attention_set_mfma(bool on);
+void conv1_set_zero_skip(bool on);
 hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s);
 void gemm_set_timeline(bool on);
 void gemm_set_big_tile(bool on);

@@ -44,6 +44,7 @@ struct Conv1Args {
     int nstrips;          // nclip * P * 5
     float invP;           // 1/P for the position -> (clip, frame) split
     unsigned long long* tl;   // debug timeline (env JG_CONV1_TL): 100 MHz stamps of workgroup 0, waves 0 and 4
+    int zskip;            // 1: all-zero input tiles (the face-mask rows) run only the two bias slots
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
                           // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
 };
@@ -66,7 +67,7 @@ constexpr int CONV_BYTES = 4 * 8 * 32 * 16;            // 16384
 constexpr int CARRY_BYTES = 8 * 32 * 16;               // 4096
 constexpr int OFF_CONV = 2 * TILE_BYTES;               // 119808
 constexpr int OFF_CARRY = OFF_CONV + 2 * CONV_BYTES;   // 152576
-constexpr int OFF_INIT = OFF_CARRY + 2 * CARRY_BYTES;  // 160768
+constexpr int OFF_INIT = OFF_CARRY + 2 * CARRY_BYTES;  // 160768: int flags[2][4] -- "loader wave w saw a non-zero byte in tile buffer b"
 constexpr int LDS_BYTES = OFF_INIT + 256;              // 161024 <= 163840
 }
 
@@ -168,7 +169,22 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // of ~40 (cvt_f32_ubyte + cvt_f16_f32 + pack); the loader waves share their SIMDs with the MFMA waves and
         // their VALU time is what the tile time was waiting for (JG_CONV1_TL=1).
         // slot element k = 3*dt + c (dt = frame 0..4, c = channel), k = 15: the bias lane, 2^-24 (= 1.0 * 2^-24).
-        auto cvt_write = [&](const C1Regs& R, char* buf) {
+        // Zero tiles: the reference blanks the face region of every frame (inference_embs.py:264,270: rows 0..y2+15,
+        // ~40 % of the crop).  A tile whose 16 x 100 x 5 source pixels are all zero contributes nothing but the bias
+        // slots: the MFMA waves then run 2 of the 49 slots (bit-identical: the other 47 add exact zeros), and a tile
+        // buffer that already holds a zero image is not rewritten.  Decided per tile from the bytes just loaded.
+        bool zero_image[2] = {false, false};       // this wave's part of tile buffer b currently holds an all-zero tile
+        int* flags = reinterpret_cast<int*>(smem + OFF_INIT);
+        auto cvt_write = [&](const C1Regs& R, char* buf, int slot) {
+            uint32_t nz = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) nz |= R.w[u][dt][0] | R.w[u][dt][1] | R.w[u][dt][2];
+            const bool any = !a.zskip || __builtin_amdgcn_ballot_w64(nz != 0) != 0;       // wave-uniform
+            if (lane == 0) flags[slot * 4 + (wave - 4)] = any ? 1 : 0;
+            if (!any && zero_image[slot]) return;
+            zero_image[slot] = !any;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u == 1 && !has1) break;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         if (ntl > 0) {
             issue(qi, R);
             next_i();
-            cvt_write(R, smem);
+            cvt_write(R, smem, 0);
             issue(qi, R);
             next_i();
         }
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             mark();
             __syncthreads();
             mark();
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(R, smem + ((t + 1) & 1) * TILE_BYTES);
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(R, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
             issue(qi, R);
             next_i();
@@ -329,6 +345,32 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const int kh = s / 7, kw = s - kh * 7;
             return *reinterpret_cast<const f16x8*>(base + (6 * q + kh) * ROW_PITCH + 32 * kw + 16 * (kw / 3));
         };
+        // D[i][jj]: jj = lane&31 -> conv column r, i = (x&3) + 8*(x>>2) + 4*h -> channel 32*chalf + 8g + 4h + (x&3).
+        // conv buffer [row mb][channel group chalf*4+g][col r][16 B], this lane's 4 channels = 8 B at +8h
+        auto epilogue = [&](const f32x16& acc, int mb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                v *= a.scale;
+                f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
+                *reinterpret_cast<f16x4*>(cbuf + ((mb * 8 + chalf * 4 + g) * 32 + r) * 16 + 8 * h) = hv;
+            }
+        };
+        const int4 fl = *reinterpret_cast<const int4*>(smem + OFF_INIT + (t & 1) * 16);
+        if (__builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) == 0) {
+            // all-zero tile (see cvt_write): only slots 0 and 1 carry anything -- the bias pair on the pad lane
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x16 acc;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                const f16x8 f0 = frag(q * 49), f1 = frag(q * 49 + 1);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[0], f0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[1], f1, acc, 0, 0, 0);
+                epilogue(acc, mb0 + 2 * q);
+            }
+            continue;
+        }
         f16x8 fr[DEPTH];
 #pragma unroll
         for (int gi = 0; gi < DEPTH; ++gi) fr[gi] = frag(gi);
@@ -347,15 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 // register, lgkmcnt(0) per MFMA) and the LDS latency is exposed 49 times per block
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // D[i][jj]: jj = lane&31 -> conv column r, i = (x&3) + 8*(x>>2) + 4*h -> channel 32*chalf + 8g + 4h + (x&3).
-            // conv buffer [row mb][channel group chalf*4+g][col r][16 B], this lane's 4 channels = 8 B at +8h
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                v *= a.scale;
-                f16x4 hv = {(f16)fmaxf(v.x, 0.f), (f16)fmaxf(v.y, 0.f), (f16)fmaxf(v.z, 0.f), (f16)fmaxf(v.w, 0.f)};
-                *reinterpret_cast<f16x4*>(cbuf + ((mb * 8 + chalf * 4 + g) * 32 + r) * 16 + 8 * h) = hv;
-            }
+            epilogue(acc, mb);
         }
     }
     __syncthreads();                           // hand the last tile's conv rows to the pool waves
@@ -372,6 +406,9 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
     const f16x8 e = *reinterpret_cast<const f16x8*>(edge + (rowi * 4 + j) * 64 + cg * 8);
     *reinterpret_cast<f16x8*>(o) = max8(*reinterpret_cast<const f16x8*>(o), e);
 }
+
+static bool g_zero_skip = true;
+void conv1_set_zero_skip(bool on) { g_zero_skip = on; }
 
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
                                f16* out_pooled, f16* edge, hipStream_t s) {
@@ -400,6 +437,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.invP = 1.0f / (float)a.P;
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;
+    a.zskip = g_zero_skip ? 1 : 0;
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
     if (want_tl && !tl && hipHostMalloc(&tl, 4096 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) tl = nullptr;
