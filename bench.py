@@ -29,6 +29,11 @@ CLIPS, FRAMES = 32, 150
 # kernel also skips the 16 duplicated edge positions, so utilisation is priced on the 154 positions it
 # really evaluates: 154 x 13904 px x 64 ch x 735 taps x 2 = 201.5 GFLOP/clip (never on padded K/tiles).
 CONV1_GFLOP_PER_CLIP = 154 * 13904 * 64 * 735 * 2 / 1e9
+# The synthetic clips carry the reference's face mask (rows 0..109 zero); conv1 detects all-zero
+# input tiles at run time and runs only their bias slots.  8 of the 22 row tiles of every strip (input rows
+# 12*rt .. 12*rt+15 <= 109) are such tiles: the roofline prices the kernel on the FLOPs it executes, and the same
+# launch is timed once more on frames without any zero row (`dense_input`).
+CONV1_EXECUTED_TILE_FRACTION = 14.0 / 22.0
 TOTAL_GFLOP_PER_CLIP = 464.9       # SURVEY 8d total, v-only
 LINEAR_GFLOP_PER_CLIP = 131.1      # GestSync transformer + ff_vid (124.7) + JEGAL gesture + align (6.4)
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 (MI355X_MICROARCH.md)
@@ -128,13 +133,31 @@ def main():
     prof = eng.profile_get()
     eng.profile(False)
     c1_ms, c1_n = prof["conv1"]
+    # the same step on frames with no zero rows (timing only): every conv1 tile is computed
+    dense = torch.randint(0, 256, frames.shape, dtype=torch.uint8, device=dev)
+    eng.extract_gesture(dense, out)
+    eng.profile_reset()
+    eng.profile(True)
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    eng.extract_gesture(dense, out)
+    torch.cuda.synchronize()
+    dense_dt = time.perf_counter() - td0
+    dprof = eng.profile_get()
+    eng.profile(False)
+    del dense
+    d1_ms, d1_n = dprof["conv1"]
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
         value = clips_total / dt
         c1_avg_s = (c1_ms / max(c1_n, 1)) * 1e-3
         clips_per_launch = args.clips / max(c1_n, 1)
-        achieved = CONV1_GFLOP_PER_CLIP * clips_per_launch / c1_avg_s / 1e3 if c1_avg_s > 0 else 0.0
+        zskip = not any(o.replace(" ", "") == "conv1_zero_skip=0" for o in args.opt)
+        exec_frac = CONV1_EXECUTED_TILE_FRACTION if zskip else 1.0
+        achieved = CONV1_GFLOP_PER_CLIP * exec_frac * clips_per_launch / c1_avg_s / 1e3 if c1_avg_s > 0 else 0.0
+        d1_avg_s = (d1_ms / max(d1_n, 1)) * 1e-3
+        dense_achieved = CONV1_GFLOP_PER_CLIP * clips_per_launch / d1_avg_s / 1e3 if d1_avg_s > 0 else 0.0
         res = {
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -143,13 +166,20 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic batch=32 gesture-only (GestSync conv + JEGAL gesture encoder), "
                                    "uint8 150x270x480x3 clips resident in HBM, seeded synthetic weights",
                        "clips_per_gpu": args.clips, "frames": FRAMES, "precision_mode": args.precision, "chunk": args.chunk,
+                       "conv1_zero_tile_skip": zskip,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU, 154 distinct positions/clip)", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": CONV1_TRAFFIC_BYTES_PER_32CLIPS * clips_per_launch / 32.0,
                          "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1d_pmc_hbm_traffic.csv (separate --pmc passes, not re-measured in this run; upper bound, includes Infinity-Cache hits); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n,
-                         "whole_path_frac": value / world * TOTAL_GFLOP_PER_CLIP / 1e3 / MFMA_PEAK_TFLOPS},
+                         "executed_tile_fraction": exec_frac,
+                         "flops_note": "achieved = executed FLOPs / launch time: all-zero input tiles (the face-mask rows, 8 of 22 row tiles of the "
+                                       "synthetic clips) run only the bias slots and are not counted",
+                         "dense_input": {"what": "same launch on uniform-noise frames without zero rows (timing only): every tile computed",
+                                         "launch_ms": d1_avg_s * 1e3, "achieved": dense_achieved, "frac": dense_achieved / MFMA_PEAK_TFLOPS,
+                                         "step_ms_with_event_overhead": dense_dt * 1e3},
+                         "whole_path_frac": value / world * (TOTAL_GFLOP_PER_CLIP - CONV1_GFLOP_PER_CLIP * (1.0 - exec_frac)) / 1e3 / MFMA_PEAK_TFLOPS},
             # second-largest consumer: all Linear-layer GEMM launches of a step taken together (algorithmic FLOPs only:
             # the hi+lo weight split of precision mode 1 is NOT counted as work)
             "roofline_linear_gemms": {"bound": "mfma", "kernel": "gemm_glds_kernel (all Linear layers of one step)",

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 ++tli;
             }
         };
-        C1Regs R;
+        C1Regs RA, RB;
         Pos qi = {s_lo, 0}, qp = {s_lo, 0};       // next tile to issue loads for; next tile to pool
         int ti = 0;
         // The frame loads are UNCONDITIONAL (past the end the last tile is simply loaded again): under an
@@ -284,27 +284,43 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             }
         };
         if (ntl > 0) {
-            issue(qi, R);
+            issue(qi, RA);                      // tile 0
             next_i();
-            cvt_write(R, smem, 0);
-            issue(qi, R);
+            cvt_write(RA, smem, 0);
+            issue(qi, RB);                      // tile 1
+            next_i();
+            issue(qi, RA);                      // tile 2
             next_i();
         }
         // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1.  We
-        //   (1) fill tile buffer (t+1)&1 from the registers loaded ONE WHOLE ITERATION ago (the vmcnt wait in
-        //       front of it is free: hipcc waits vmcnt(0) whenever loads and stores are both pending),
-        //   (2) reload the same registers with tile t+2,
-        //   (3) pool tile t-1 (its stores go last: their acknowledgement is what the next vmcnt(0) sees).
-        for (int t = 0; t < ntl; ++t) {
+        //   (1) fill tile buffer (t+1)&1 from the registers loaded TWO ITERATIONS ago (zero tiles make an iteration
+        //       shorter than an HBM round trip; hipcc waits vmcnt(0) there whenever loads and stores are both pending),
+        //   (2) reload the same registers with tile t+3,
+        //   (3) pool tile t-1 (its stores go last).
+        // Two register sets, so the loop is unrolled by two (a runtime-selected set would be a phi again).
+        int t = 0;
+        while (t < ntl) {
             mark();
             __syncthreads();
             mark();
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(R, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
-            issue(qi, R);
+            issue(qi, RB);
             next_i();
             mark();
             if (t > 0 && !(a.dbg & 4)) { pool(qp, t - 1); advance(qp); }
+            ++t;
+            if (t >= ntl) break;
+            mark();
+            __syncthreads();
+            mark();
+            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            mark();
+            issue(qi, RA);
+            next_i();
+            mark();
+            if (!(a.dbg & 4)) { pool(qp, t - 1); advance(qp); }
+            ++t;
         }
         __syncthreads();                       // the MFMA waves have finished the last tile
         if (ntl > 0 && !(a.dbg & 4)) pool(qp, ntl - 1);
