@@ -214,8 +214,24 @@ int make_ln(jg_handle* h, const std::string& wname, const std::string& bname, in
 
 // conv weight [O][I][KT][KH][KW] (+ optional eval BatchNorm) -> [O][Kpad] with k = ((kh*KW+kw)*slot + (kt*I + c)),
 // slot = channels per (kh,kw) position after padding (16 for conv1's 5x3 temporal stack, I otherwise).
+// Tap order of a conv layer's K axis: natural (kh, kw) or, for strided layers run with `reorder`, grouped by
+// parity class (kh % SH, kw % SW) -- see ConvGeom::taps.  Used by BOTH the weight packing and the geometry.
+std::vector<std::pair<int, int>> tap_order(int KH, int KW, int SH, int SW, bool reorder) {
+    std::vector<std::pair<int, int>> t;
+    if (!reorder || KH * KW > 32) {
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KW; ++kw) t.push_back({kh, kw});
+        return t;
+    }
+    for (int ph = 0; ph < SH; ++ph)
+        for (int pw = 0; pw < SW; ++pw)
+            for (int kh = ph; kh < KH; kh += SH)
+                for (int kw = pw; kw < KW; kw += SW) t.push_back({kh, kw});
+    return t;
+}
+
 int make_conv(jg_handle* h, const std::string& conv, const std::string& bn, int O, int I, int KT, int KH, int KW,
-              int slot, int kpad, Lin* L) {
+              int slot, int kpad, Lin* L, int SH = 1, int SW = 1, bool reorder = false) {
     const HostTensor *w, *b;
     RET(need(h, conv + ".weight", (int64_t)O * I * KT * KH * KW, &w));
     RET(need(h, conv + ".bias", O, &b));
@@ -233,14 +249,15 @@ int make_conv(jg_handle* h, const std::string& conv, const std::string& bn, int 
     }
     const int K = kpad > 0 ? kpad : KH * KW * slot;
     std::vector<float> p((size_t)O * K, 0.f);
+    const auto order = tap_order(KH, KW, SH, SW, reorder);
     for (int o = 0; o < O; ++o)
         for (int c = 0; c < I; ++c)
             for (int kt = 0; kt < KT; ++kt)
-                for (int kh = 0; kh < KH; ++kh)
-                    for (int kw = 0; kw < KW; ++kw) {
-                        const float v = w->v[((((size_t)o * I + c) * KT + kt) * KH + kh) * KW + kw] * s[o];
-                        p[(size_t)o * K + (size_t)(kh * KW + kw) * slot + kt * I + c] = v;
-                    }
+                for (size_t t = 0; t < order.size(); ++t) {
+                    const int kh = order[t].first, kw = order[t].second;
+                    const float v = w->v[((((size_t)o * I + c) * KT + kt) * KH + kh) * KW + kw] * s[o];
+                    p[(size_t)o * K + t * slot + kt * I + c] = v;
+                }
     return pack_matrix(h, p, shift, O, K, LK_CONV, L);
 }
 
@@ -265,10 +282,11 @@ int make_annotated_layer(jg_handle* h, const std::string& p, int D, int Dff, Enc
 
 int finalize_gestsync(jg_handle* h) {
     RET(make_conv(h, "net_vid.conv1", "net_vid.bn1", 64, 3, 5, 7, 7, 16, 0, &h->c1));
-    RET(make_conv(h, "net_vid.conv2", "net_vid.bn2", 128, 64, 1, 5, 5, 64, 0, &h->c2));
-    RET(make_conv(h, "net_vid.conv3", "net_vid.bn3", 256, 128, 1, 3, 3, 128, 0, &h->c3));
-    RET(make_conv(h, "net_vid.conv4", "net_vid.bn4", 256, 256, 1, 3, 3, 256, 0, &h->c4));
-    RET(make_conv(h, "net_vid.conv5", "net_vid.bn5", 256, 256, 1, 3, 3, 256, 0, &h->c5));
+    // conv2..conv5: taps grouped by stride parity class (ConvGeom::taps); gs_conv_stack builds the same geometry
+    RET(make_conv(h, "net_vid.conv2", "net_vid.bn2", 128, 64, 1, 5, 5, 64, 0, &h->c2, 2, 2, true));
+    RET(make_conv(h, "net_vid.conv3", "net_vid.bn3", 256, 128, 1, 3, 3, 128, 0, &h->c3, 2, 2, true));
+    RET(make_conv(h, "net_vid.conv4", "net_vid.bn4", 256, 256, 1, 3, 3, 256, 0, &h->c4, 1, 2, true));
+    RET(make_conv(h, "net_vid.conv5", "net_vid.bn5", 256, 256, 1, 3, 3, 256, 0, &h->c5, 1, 1, true));
     RET(make_conv(h, "net_vid.fc6", "net_vid.bn6", 512, 256, 1, 4, 4, 256, 0, &h->fc6));
     RET(upload(h, std::vector<float>(64, 1.0f / 255.0f), &h->c1_scale255));
     {   // slot-major copy of the packed conv1 panel for conv1_direct_kernel: Wd[s][o][e] = W[o][s*16+e]
@@ -373,8 +391,16 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     return timed(h, stage, [&] { return launch_gemm(a, conv, h->stream); });
 }
 
-ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW) {
+ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, bool reorder = false) {
     ConvGeom g;
+    g.taps[0] = g.taps[1] = g.taps[2] = g.taps[3] = 0;
+    g.tap_table = 0;
+    if (reorder && KH * KW <= 32) {
+        const auto order = tap_order(KH, KW, SH, SW, true);
+        for (size_t t = 0; t < order.size(); ++t)
+            g.taps[t >> 3] |= (unsigned long long)((order[t].first << 4) | order[t].second) << ((t & 7) * 8);
+        g.tap_table = 1;
+    }
     g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.SH = SH; g.SW = SW; g.PH = PH; g.PW = PW;
     g.OH = (H + 2 * PH - KH) / SH + 1;
     g.OW = (W + 2 * PW - KW) / SW + 1;
@@ -393,10 +419,10 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     const long NF = (long)nclip * P;
     f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
-    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0);            // 20 x 37
-    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1);           // 10 x 19
-    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1);           // 10 x 10
-    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1);           // 10 x 10
+    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);      // 20 x 37   (taps in parity-class order, as packed)
+    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);     // 10 x 19
+    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);     // 10 x 10
+    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);     // 10 x 10
     RET(wsalloc(h, (size_t)NF * 43 * 78 * 64, &p1));
     RET(wsalloc(h, (size_t)NF * 20 * 37 * 128, &o2));
     RET(wsalloc(h, (size_t)NF * 10 * 19 * 256, &o3));

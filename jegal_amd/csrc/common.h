@@ -16,7 +16,28 @@ struct ConvGeom {
     int OH, OW;           // output spatial size
     int KH, KW, SH, SW, PH, PW;
     int cshift;           // log2(C)
+    // K order of the taps: k = (p, c) with tap p -> (kh, kw) = taps byte p (kh << 4 | kw), or the natural
+    // p = kh*KW + kw when tap_table == 0.  Strided layers list their taps by parity class (kh % SH, kw % SW):
+    // consecutive taps of a class touch the same input pixels shifted by whole output positions, so the re-reads
+    // of a k-loop hit the L2 instead of thrashing it (conv2: 25 taps, 4 classes of 9/6/6/4).  The packed weights
+    // use the same order (api.hip:make_conv).
+    unsigned long long taps[4];
+    int tap_table;
 };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void tap_decode(const ConvGeom& g, int p, int& kh, int& kw) {
+    if (g.tap_table) {
+        const unsigned long long w = p < 8 ? g.taps[0] : p < 16 ? g.taps[1] : p < 24 ? g.taps[2] : g.taps[3];
+        const int code = (int)(w >> ((p & 7) * 8)) & 0xff;
+        kh = code >> 4;
+        kw = code & 15;
+    } else {
+        kh = p / g.KW;
+        kw = p - kh * g.KW;
+    }
+}
+#endif
 
 // out[m][n] = epi( sum_k A[m][k] * (Wh[n][k] + Wl[n][k]) )
 // epi(v) = relu?( v*scale[n] + bias[n] + res[(m % res_mod)][n] )

@@ -74,8 +74,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         if (CONV) {
             ci = k & (a.g.C - 1);
             const int kp = k >> a.g.cshift;
-            kh = kp / a.g.KW;
-            kw = kp - kh * a.g.KW;
+            tap_decode(a.g, kp, kh, kw);
         }
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
@@ -243,6 +242,13 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     // tail -- LDS-DMA cannot predicate, but it can read zeros.
     const f16* xsrc[XI];
     int xih[XI], xiw[XI], xchunk[XI];
+    long xpix[XI];          // CONV, C % 64 == 0: element offset of (xih, xiw, chunk) inside the image (may be negative: padding)
+    // CONV with C % 64 == 0: a 64-wide k-tile is 64 channels of ONE tap, so (kh, kw, c0) are wave-uniform and simply
+    // advance with the k-tiles (stage() is always called for kt = 0, 1, 2, ... of a tile).  The general path below
+    // decodes k per DMA instruction with a runtime division -- ~30 VALU instructions x XI per k-tile on every wave,
+    // on the same SIMDs as the MFMAs.
+    const bool tap_uniform = CONV && (a.g.C & 63) == 0;
+    int tidx = 0, tc0 = 0;
     const f16* whsrc[WI];
     const f16* wlsrc[WI];
     int wchunk[WI];
@@ -264,8 +270,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 xih[i] = oh * a.g.SH - a.g.PH;
                 xiw[i] = ow * a.g.SW - a.g.PW;
                 xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
+                xpix[i] = ((long)xih[i] * a.g.W + xiw[i]) * a.g.C + c * 8;
             } else {
                 xih[i] = xiw[i] = 0;
+                xpix[i] = 0;
                 xsrc[i] = a.A + (long)m * a.lda + c * 8;
             }
         }
@@ -283,21 +291,42 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
         const int k0 = kt * 64;
+        if (CONV && tap_uniform) {
+            if (kt == 0) tidx = tc0 = 0;
+            int tkh, tkw;
+            tap_decode(a.g, tidx, tkh, tkw);
+            const long tapoff = ((long)tkh * a.g.W + tkw) * a.g.C + tc0;
+            const bool kin = k0 < a.K;
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const f16* src;
-            if (CONV) {
-                const int k = k0 + xchunk[i] * 8;
-                const int ci = k & (a.g.C - 1);
-                const int kp = k >> a.g.cshift;
-                const int kh = kp / a.g.KW, kw = kp - kh * a.g.KW;
-                const int ih = xih[i] + kh, iw = xiw[i] + kw;
-                const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
-                src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
-            } else {
-                src = xsrc[i] + k0;
+            for (int i = 0; i < XI; ++i) {
+                const int ih = xih[i] + tkh, iw = xiw[i] + tkw;
+                const bool ok = kin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+                const f16* src = ok ? xsrc[i] + (xpix[i] + tapoff) : zeros;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
+            tc0 += 64;
+            if (tc0 == a.g.C) {
+                tc0 = 0;
+                ++tidx;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const f16* src;
+                if (CONV) {
+                    const int k = k0 + xchunk[i] * 8;
+                    const int ci = k & (a.g.C - 1);
+                    const int kp = k >> a.g.cshift;
+                    int kh, kw;
+                    tap_decode(a.g, kp, kh, kw);
+                    const int ih = xih[i] + kh, iw = xiw[i] + kw;
+                    const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+                    src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
+                } else {
+                    src = xsrc[i] + k0;
+                }
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
@@ -878,7 +907,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs a, int
                 const int k = k0 + xchunk[i] * 8;
                 const int ci = k & (a.g.C - 1);
                 const int kp = k >> a.g.cshift;
-                const int kh = kp / a.g.KW, kw = kp - kh * a.g.KW;
+                int kh, kw;
+                    tap_decode(a.g, kp, kh, kw);
                 const int ih = xih[i] + kh, iw = xiw[i] + kw;
                 const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
