@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
         const int mb = cm0 + wm * (16 * MI) + frow;
-        constexpr bool SPREAD = LNF;      // measured: -16 % on the 128x512 LN kernel (K = 2048), +2-4 % on the 256x256 tiles, register spills on CONV
+        constexpr bool SPREAD = LNF || CONV;      // measured: -16 % on the 128x512 LN kernel (K = 2048), +2-4 % on the 256x256 tiles, register spills on CONV
         constexpr bool PREFETCH_RES = MI <= 4;        // 128x64 wave tiles have no registers to spare for it
 
         f32x4 rs[4][PREFETCH_RES ? MI : 1];
