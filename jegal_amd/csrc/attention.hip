@@ -278,6 +278,147 @@ __global__ __launch_bounds__(256) void attn_mfma_s32_kernel(const f16* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for 32 < S <= 160 (JEGAL gesture encoder: S = T = 150 frames), dk = 64, optional key mask.
+// One workgroup per (sequence, head) pair, one wave per block of 32 queries (NB = ceil(S/32) waves).  K (row-major)
+// and V (transposed) of the head are staged in LDS once per pair; every wave computes its 32 x S score block
+// S^T = K Q^T into NB accumulator tiles, softmaxes over its registers and its partner lane, and multiplies by
+// V^T straight from the accumulators (same operand trick and fp16 hi+lo probabilities as attn_mfma_s32_kernel).
+// masked_fill(mask == 0, -1e9) as in modules.py:66-67; keys >= S get -inf.
+template <int NB>
+__global__ __launch_bounds__(64 * NB) void attn_mfma_kernel(const f16* __restrict__ qkv, const float* __restrict__ keymask,
+                                                            int S, int H, f16* __restrict__ out) {
+    constexpr int DK = 64, SP = 32 * NB, K_PITCH = 144, VT_PITCH = SP * 2 + 8, O_PITCH = 144, NT = 64 * NB;
+    __shared__ __attribute__((aligned(16))) char sK[SP * K_PITCH];
+    __shared__ __attribute__((aligned(16))) char sVt[64 * VT_PITCH];
+    __shared__ __attribute__((aligned(16))) float sM[SP];
+    static_assert(K_PITCH == O_PITCH, "the output tiles reuse the K image");
+    char* sOall = sK;           // after the barrier that follows the score phase
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x;
+    const int b = pair / H, head = pair - b * H;
+    const int D = H * DK;
+    const long ld = 3L * D;
+    const f16* base = qkv + (long)b * S * ld + head * DK;
+    const int r31 = lane & 31, hh = lane >> 5;
+
+    // ---- stage K (row-major), V (transposed) and the mask row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = tid + NT * r, row = c >> 3, part = c & 7;          // SP rows x 8 chunks = 4 * NT
+        const int rc = row < S ? row : S - 1;
+        const f16* src = base + (long)rc * ld + part * 8;
+        const f16x8 kk = *reinterpret_cast<const f16x8*>(src + D);
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(src + 2 * D);
+        *reinterpret_cast<f16x8*>(sK + row * K_PITCH + part * 16) = kk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(sVt + (part * 8 + e) * VT_PITCH + row * 2) = vv[e];
+    }
+    for (int j = tid; j < SP; j += NT) sM[j] = j < S ? (keymask ? keymask[(long)b * S + j] : 1.f) : -1.f;   // -1: beyond S
+    // this wave's queries: B operand straight from global memory
+    const int q0 = 32 * wave;
+    const int qr = q0 + r31 < S ? q0 + r31 : S - 1;
+    f16x8 qB[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qB[s] = *reinterpret_cast<const f16x8*>(base + (long)qr * ld + 16 * s + 8 * hh);
+    __syncthreads();
+
+    // ---- scores: NB tiles of 32 keys x 32 queries
+    f32x16 sc[NB];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 kA = *reinterpret_cast<const f16x8*>(sK + (32 * kb + r31) * K_PITCH + (16 * s + 8 * hh) * 2);
+            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kA, qB[s], sc[kb], 0, 0, 0);
+        }
+    }
+    // ---- softmax over the keys: register i of tile kb <-> key 32kb + (i&3) + 8(i>>2) + 4*hh
+    const float scale = 0.125f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(&sM[32 * kb + 8 * g + 4 * hh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = sc[kb][4 * g + e] * scale;
+                v = mk[e] < 0.f ? -INFINITY : (mk[e] == 0.f ? -1e9f : v);
+                sc[kb][4 * g + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sc[kb][i] = __expf(sc[kb][i] - mx);
+            sum += sc[kb][i];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+
+    // ---- O^T = V^T P^T
+    f32x16 o[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 pH, pL;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = sc[kb][4 * (2 * s + (j >> 2)) + (j & 3)] * inv;
+                const f16 hi = (f16)pv;
+                pH[j] = hi;
+                pL[j] = (f16)(pv - (float)hi);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const char* vp = sVt + (r31 + 32 * blk) * VT_PITCH + (32 * kb + 16 * s + 4 * hh) * 2;
+                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
+                const f16x8 vA = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pH, o[blk], 0, 0, 0);
+                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pL, o[blk], 0, 0, 0);
+            }
+        }
+    // ---- back to [query][d] rows through this wave's LDS slice (aliases the K image: every wave is done with K)
+    __syncthreads();
+    char* sO = sOall + wave * (32 * O_PITCH);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f16x4 hv = {(f16)o[blk][4 * g], (f16)o[blk][4 * g + 1], (f16)o[blk][4 * g + 2], (f16)o[blk][4 * g + 3]};
+            *reinterpret_cast<f16x4*>(sO + r31 * O_PITCH + (32 * blk + 8 * g + 4 * hh) * 2) = hv;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f16* obase = out + ((long)b * S + q0) * D + head * DK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+        if (q0 + row < S) *reinterpret_cast<f16x8*>(obase + (long)row * D + part * 8) = *reinterpret_cast<const f16x8*>(sO + row * O_PITCH + part * 16);
+    }
+}
+
+template <int NB>
+static hipError_t launch_attn_mfma(const f16* qkv, const float* keymask, long npairs, int S, int H, f16* out, hipStream_t s) {
+    hipLaunchKernelGGL((attn_mfma_kernel<NB>), dim3((unsigned)npairs), dim3(64 * NB), 0, s, qkv, keymask, S, H, out);
+    return hipGetLastError();
+}
+
 static bool g_attn_mfma = true;
 void attention_set_mfma(bool on) { g_attn_mfma = on; }
 
@@ -287,6 +428,15 @@ hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, 
     if (g_attn_mfma && S <= 32 && dk == 64 && !keymask && npairs < (1L << 31)) {
         hipLaunchKernelGGL(attn_mfma_s32_kernel, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out);
         return hipGetLastError();
+    }
+    if (g_attn_mfma && S <= 160 && dk == 64 && npairs < (1L << 31)) {      // S <= 32 with a key mask: one query block
+        switch ((S + 31) / 32) {
+            case 1: return launch_attn_mfma<1>(qkv, keymask, npairs, S, H, out, s);
+            case 2: return launch_attn_mfma<2>(qkv, keymask, npairs, S, H, out, s);
+            case 3: return launch_attn_mfma<3>(qkv, keymask, npairs, S, H, out, s);
+            case 4: return launch_attn_mfma<4>(qkv, keymask, npairs, S, H, out, s);
+            default: return launch_attn_mfma<5>(qkv, keymask, npairs, S, H, out, s);
+        }
     }
     dim3 grid, block;
     int G = 1;
