@@ -367,6 +367,11 @@ struct Epi {
     int relu = 0;
     const LNp* ln = nullptr;      // fused residual + LayerNorm epilogue (when the GEMM can: see gemm_ln_fusable)
     int ln_flavour = LN_STD;
+    // tiled token stream of the fused GestSync transformer (common.h): residual in / LayerNorm out planes, tiled A operand
+    const f16* res16 = nullptr;
+    const signed char* res8 = nullptr;
+    signed char* out8 = nullptr;
+    int a_tiled = 0;
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -381,6 +386,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     a.out32 = e.out32; a.out16 = e.out16; a.ldc = e.ldc ? e.ldc : L.N;
     a.relu = e.relu;
     if (e.ln) { a.ln_w = e.ln->w; a.ln_b = e.ln->b; a.ln_flavour = e.ln_flavour; }
+    a.res16 = e.res16; a.res8 = e.res8; a.out8 = e.out8; a.a_tiled = e.a_tiled;
     const bool conv = g != nullptr;
     if (h->calib && L.bc && !conv) {
         Lin& Lm = const_cast<Lin&>(L);
@@ -471,34 +477,36 @@ bool gs_fused_plan(const jg_handle* h, int M) {
 }
 inline size_t pad128(size_t rows) { return (rows + 127) / 128 * 128; }
 
-// x32/x16 hold pad128(M) rows; with `tiled` x32 is the tiled residual stream (launch_window_gather(..., tiled = 1)).
+// x32/x16 hold pad128(M) rows.  With `tiled` (gs_fused_plan) the token stream is the tiled fp16 plane x16 plus the 8-bit
+// correction plane stored in x32's memory (launch_window_gather(..., tiled = 1)); otherwise fp32 rows + fp16 rows.
 int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled) {
     const int M = nseq * S;
     f16 *qkv, *att, *hid;
     RET(wsalloc(h, (size_t)M * 1536, &qkv));
     RET(wsalloc(h, (size_t)M * 512, &att));
     RET(wsalloc(h, (size_t)M * 2048, &hid));
+    signed char* d8 = reinterpret_cast<signed char*>(x32);
     for (int l = 0; l < 6; ++l) {
         const EncLayer& L = h->gs_layers[l];
         Epi e;
-        e.out16 = qkv;
+        e.out16 = qkv; e.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
         RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
         // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue (row-wide
-        // 128x512 tiles, tiled fp32 residual stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
+        // 128x512 tiles, tiled fp16 + 8-bit token stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
         auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
             Epi r;
-            r.res = x32; r.ldr = 512; r.out32 = x32;
             if (tiled) {
-                r.out16 = x16; r.ln = &ln; r.ln_flavour = LN_STD;
+                r.res16 = x16; r.res8 = d8; r.out16 = x16; r.out8 = d8; r.ln = &ln; r.ln_flavour = LN_STD;
                 return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
             }
+            r.res = x32; r.ldr = 512; r.out32 = x32;
             RET(gemm(h, JG_ST_GEMM, A, lda, M, W, r));
             return timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, ln.w, ln.b, M, 512, LN_STD, 0, x32, x16, h->stream); });
         };
         RET(proj_ln(att, 512, L.out, L.n1));
         Epi f;
-        f.relu = 1; f.out16 = hid;
+        f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.ff1, f));
         RET(proj_ln(hid, 2048, L.ff2, L.n2));
     }
@@ -532,7 +540,7 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(gs_transformer(h, x32, x16, nseq, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
-        Epi f; f.relu = 1; f.out16 = hid;
+        Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
         RET(timed(h, JG_ST_MISC, [&] { return launch_group_mean(hid, nseq, S, 512, mean16, h->stream); }));
         Epi o; o.out32 = out_feats + (size_t)b0 * T * 1024;
@@ -564,7 +572,7 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
         RET(gs_transformer(h, x32, x16, nb, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)M * 1024, &full));
-        Epi f; f.relu = 1; f.out16 = hid;
+        Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
         Epi o; o.out32 = full;
         RET(gemm(h, JG_ST_GEMM, hid, 512, M, h->ff2, o));
@@ -950,7 +958,9 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
     a.M = M; a.N = N; a.K = K; a.bias = bias; a.ldc = N; a.relu = (mode >> 2) & 1;
     if (mode & 2) { a.res = x32; a.ldr = N; a.out32 = x32; } else { a.out16 = o16; }
     if (mode & 8) {      // residual + LayerNorm fused (N = 512): gamma/beta = the zero bias vector, timing only
-        a.out16 = o16; a.ln_w = bias; a.ln_b = bias; a.ln_flavour = LN_STD;
+        a.res = nullptr; a.out32 = nullptr;
+        a.res16 = o16; a.res8 = reinterpret_cast<signed char*>(x32); a.out16 = o16; a.out8 = reinterpret_cast<signed char*>(x32);
+        a.ln_w = bias; a.ln_b = bias; a.ln_flavour = LN_STD;
     }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));

@@ -62,7 +62,39 @@ struct GemmArgs {
     const float* ln_w;    // nullptr: no LayerNorm
     const float* ln_b;
     int ln_flavour;       // LN_STD / LN_ANNOTATED
+    // Tiled token stream of the fused GestSync transformer (see res_* below): with ln_w the residual comes from
+    // (res16, res8) and the LayerNorm output goes to (out16, out8), all in the tiled order; a_tiled: the A operand
+    // of a plain GEMM (K == 512) is such a tiled fp16 plane.
+    const f16* res16;
+    const signed char* res8;
+    signed char* out8;
+    int a_tiled;
 };
+
+// ---- tiled token stream (N = 512 columns, row tiles of 128) -----------------------------------------------------
+// The residual stream of the fused transformer is kept as fp16 + an 8-bit correction instead of fp32 (3 instead of
+// 4 bytes per element to read, 3 instead of 6 to write next to the fp16 copy the next GEMM needs anyway):
+//   x  =  x16 + q * ulp(x16)/256,   q = round((x - x16) * 256/ulp(x16)) in [-127, 127]
+// i.e. 8 more mantissa bits than fp16 (relative error <= 2^-19 per LayerNorm output, 12 of them per forward pass;
+// the embedding tolerance is 1e-3).  Both planes are stored in the MFMA fragment order of the 128x512 LN kernel:
+//   x16t element (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + ((n&63)>>4)*256 + (m&15)*16 + (n&15),  R = m>>7
+//        (a wave's 8-byte accesses of one (j, i) block are one contiguous 512 B; a 64-wide k-tile of a 128-row
+//         panel is one contiguous 16 KB -> the consumer GEMMs' LDS-DMA reads it with a_tiled addressing)
+//   d8t  byte    (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + lane*16 + ((n&63)>>4)*4 + (n&3),
+//        lane = ((n&15)>>2)*16 + (m&15)   (one 16-byte access per lane and 16-row block)
+#ifdef __HIPCC__
+__device__ __forceinline__ float res_dec(f16 h, int q) {
+    unsigned E = ((unsigned)__builtin_bit_cast(unsigned short, h) >> 10) & 31u;
+    E = E ? E : 1u;
+    return (float)h + (float)q * __builtin_bit_cast(float, (E + 94u) << 23);            // 2^(E-33) = ulp(h)/256
+}
+__device__ __forceinline__ int res_enc(float y, f16 h) {
+    unsigned E = ((unsigned)__builtin_bit_cast(unsigned short, h) >> 10) & 31u;
+    E = E ? E : 1u;
+    const float q = rintf((y - (float)h) * __builtin_bit_cast(float, (160u - E) << 23));   // * 2^(33-E)
+    return (int)fminf(fmaxf(q, -127.f), 127.f);
+}
+#endif
 
 enum { LN_STD = 0, LN_ANNOTATED = 1 };
 

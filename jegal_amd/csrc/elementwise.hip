@@ -108,18 +108,23 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
         pp = pp < 0 ? 0 : (pp > P - 1 ? P - 1 : pp);
         f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + pp) * D + d4 * 4);
         v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
-        long o32 = idx * 4;
+        const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
         if (tiled) {
-            // fp32 residual stream in the fused GEMM+LayerNorm kernel's fragment order (gemm.hip, LNF epilogue):
-            // [row tile of 128][wave = col/64][j = row%128/16][i = col%64/16][lane = (col%16/4)*16 + row%16] float4
+            // token stream of the fused GEMM+LayerNorm kernel: tiled fp16 plane + 8-bit correction plane
+            // (layouts and res_enc in common.h); x32 is the correction plane here
             const long row = idx / dv;
             const int col = d4 * 4;
             const int rr = (int)(row & 127);
-            o32 = (row >> 7) * (128 * 512) + ((((col >> 6) * 8 + (rr >> 4)) * 4 + ((col & 63) >> 4)) * 64 + ((col & 15) >> 2) * 16 + (rr & 15)) * 4;
+            const long blk = (row >> 7) * 65536 + (col >> 6) * 8192 + (rr >> 4) * 1024;
+            *reinterpret_cast<f16x4*>(x16 + blk + ((col & 63) >> 4) * 256 + (rr & 15) * 16 + (col & 15)) = h;
+            const unsigned dw = (unsigned)(res_enc(v.x, h[0]) & 0xff) | ((unsigned)(res_enc(v.y, h[1]) & 0xff) << 8) |
+                                ((unsigned)(res_enc(v.z, h[2]) & 0xff) << 16) | ((unsigned)(res_enc(v.w, h[3]) & 0xff) << 24);
+            const int ln = ((col & 15) >> 2) * 16 + (rr & 15);
+            *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(x32) + blk + ln * 16 + ((col & 63) >> 4) * 4) = dw;
+        } else {
+            *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
+            *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
         }
-        *reinterpret_cast<f32x4*>(x32 + o32) = v;
-        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-        *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
     }
 }
 

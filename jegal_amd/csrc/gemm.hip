@@ -269,7 +269,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)xih[i] * a.g.W + xiw[i]) * a.g.C + c * 8;
             } else {
                 xih[i] = xiw[i] = 0;
-                xsrc[i] = a.A + (long)m * a.lda + c * 8;
+                xsrc[i] = a.a_tiled ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) * 1024 + (m & 15) * 16 + (c >> 1) * 256 + (c & 1) * 8
+                                    : a.A + (long)m * a.lda + c * 8;
             }
         }
 #pragma unroll
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
             } else {
-                src = xsrc[i] + sk0;
+                src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
         } else if (p < XI + WI) {
@@ -365,18 +366,30 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             ++tli;
         }
     };
-    // LNF: the accumulators start from the fp32 residual, loaded in fragment order from the tiled residual stream
-    // (see the epilogue) one tile ahead, so its HBM latency hides behind the previous tile's stores.
+    // LNF: the accumulators start from the residual.  The token stream is the tiled fp16 + 8-bit pair of common.h
+    // (res_dec / res_enc): its raw bits are loaded one tile ahead (4 x 8 B + 16 B per 16-row block and lane, every
+    // access a contiguous 512 B / 1 KB per wave instruction) and expanded to fp32 right before the k loop.
+    // The raw bits of a 16-row block (4 x 8 B of fp16, 16 B of corrections = 12 registers) are parked IN the 16
+    // accumulator registers of that block, which are dead between the block's stores and the next tile's k loop:
+    //   acc[0][j] = {x16 i=0 (2 regs), x16 i=3 (2 regs)},  acc[1][j].xy = x16 i=1,  acc[2][j].xy = x16 i=2,  acc[3][j] = d8.
+    // (As separate arrays hipcc spilled every loaded value to scratch right behind its load.)
     f32x4 acc[4][MI];
-    auto res_tile = [&](const float* base, int tm0) -> const float* {
-        return base + (long)(tm0 / BM) * (BM * BN) + (long)wn * (MI * 4 * 256) + lane * 4;
+    auto x16t_off = [&](int tm0) -> long { return (long)(tm0 / BM) * 65536 + (long)wn * 8192 + frow * 16 + fq * 4; };     // + j*1024 + i*256
+    auto d8t_off = [&](int tm0) -> long { return (long)(tm0 / BM) * 65536 + (long)wn * 8192 + lane * 16; };               // + j*1024
+    auto asf = [](unsigned v) -> float { return __builtin_bit_cast(float, v); };
+    auto load_stream = [&](int tm0, int j) __attribute__((always_inline)) {
+        const f16* xp = a.res16 + x16t_off(tm0) + j * 1024;
+        const uint2 r0 = *reinterpret_cast<const uint2*>(xp), r1 = *reinterpret_cast<const uint2*>(xp + 256);
+        const uint2 r2 = *reinterpret_cast<const uint2*>(xp + 512), r3 = *reinterpret_cast<const uint2*>(xp + 768);
+        const uint4 dq = *reinterpret_cast<const uint4*>(a.res8 + d8t_off(tm0) + j * 1024);
+        acc[0][j] = f32x4{asf(r0.x), asf(r0.y), asf(r3.x), asf(r3.y)};
+        acc[1][j] = f32x4{asf(r1.x), asf(r1.y), 0.f, 0.f};
+        acc[2][j] = f32x4{asf(r2.x), asf(r2.y), 0.f, 0.f};
+        acc[3][j] = f32x4{asf(dq.x), asf(dq.y), asf(dq.z), asf(dq.w)};
     };
     if constexpr (LNF) {
-        const float* rp = res_tile(a.res, m0);
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(rp + (j * 4 + i) * 256);
+        for (int j = 0; j < MI; ++j) load_stream(m0, j);
     }
     int pending = 0;           // the k-tile-0 DMA of this tile is older than exactly `pending` epilogue stores (0: unknown)
     while (true) {
@@ -408,6 +421,21 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 if (PREFETCH_RES) rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 
+        if constexpr (LNF) {
+            // expand the parked token-stream bits of this tile into fp32 accumulators (res_dec, common.h)
+            auto asu = [](float v) -> unsigned { return __builtin_bit_cast(unsigned, v); };
+            auto h2 = [](unsigned w, int hi) -> f16 { return __builtin_bit_cast(f16, (unsigned short)(hi ? w >> 16 : w & 0xffffu)); };
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const f32x4 a0 = acc[0][j], a1 = acc[1][j], a2 = acc[2][j], a3 = acc[3][j];
+                const unsigned xw[4][2] = {{asu(a0.x), asu(a0.y)}, {asu(a1.x), asu(a1.y)}, {asu(a2.x), asu(a2.y)}, {asu(a0.z), asu(a0.w)}};
+                const unsigned dw[4] = {asu(a3.x), asu(a3.y), asu(a3.z), asu(a3.w)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = f32x4{res_dec(h2(xw[i][0], 0), (int)(signed char)(dw[i] & 0xff)), res_dec(h2(xw[i][0], 1), (int)(signed char)((dw[i] >> 8) & 0xff)),
+                                      res_dec(h2(xw[i][1], 0), (int)(signed char)((dw[i] >> 16) & 0xff)), res_dec(h2(xw[i][1], 1), (int)(signed char)(dw[i] >> 24))};
+            }
+        }
         for (int kt = 0; kt < nk; ++kt) {
             const bool pre = kt + 1 < nk;
             if (pre) stage_begin(kt + 1);
@@ -484,31 +512,29 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             // The tile spans the whole row (BN == N == 512, wave wn owns columns wn*64..+63): row statistics are a
             // shuffle over the 4 lanes of a row inside the wave plus an 8-way exchange through LDS (stage 1 is idle
             // here).  Two-pass (mean, then centred variance) like nn.LayerNorm.
-            //
-            // The fp32 residual stream (a.res in, a.out32 out, normally the same buffer) is NOT row-major: it is
-            // stored in this kernel's own fragment order -- tile R = m/128, then [wave wn][j][i][lane] float4 --
-            // so every residual load and every fp32 store is one contiguous 1 KB per wave instruction, with no
-            // LDS transposition.  launch_window_gather(..., tiled) writes the initial stream in that order; nothing
-            // else reads it.  The residual of the NEXT tile is loaded straight into the accumulators as soon as
-            // the row block j of this tile has been stored (no spare registers, latency hidden behind the rest of
-            // the epilogue).  The fp16 copy (the next GEMM's activation operand) is row-major and goes through
-            // the LDS transposition like every fp16 output.  Whole 128-row tiles are written: out16 and the
-            // stream hold ceil(M/128)*128 rows.
-            constexpr int TP16 = 144;
+            // Input and output token stream: the tiled fp16 + 8-bit pair (common.h) in this kernel's own fragment
+            // order, normally in place.  As soon as the 16-row block j of this tile has been stored, the raw bits of
+            // block j of the NEXT tile are loaded (no spare registers are needed for a whole tile of residual, the
+            // HBM latency hides behind the rest of the epilogue); that tile's first DMA goes in front of block JD and
+            // is retired with a counted wait.  Whole 128-row tiles are written: the planes hold ceil(M/128)*128 rows.
+            // bias / gamma / beta come from LDS (3 x 512 floats, re-staged per tile: the k loop owns the LDS).
             constexpr int JD = 2;                                         // row block in front of which the next tile's DMA goes
             float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
-            char* tsc = smem + STAGE + 2 * 8 * BM * 4 + wave * (16 * TP16);
-            const int nbase = cn0 + wn * 64 + fq * 4;
-            f32x4 biv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) biv[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nbase + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float* lnp = red + 2 * 8 * BM;                                // [3][BN]: bias, gamma, beta
+            for (int c = t; c < BN; c += 512) {
+                lnp[c] = a.bias ? a.bias[c] : 0.f;
+                lnp[BN + c] = a.ln_w[c];
+                lnp[2 * BN + c] = a.ln_b[c];
+            }
+            __syncthreads();
+            const int ncol = wn * 64 + fq * 4;                            // + i*16: this lane's 4 columns of block i
             float rsum[MI];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 float sj = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = acc[i][j] + biv[i];
+                    const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(lnp + ncol + i * 16);
                     acc[i][j] = v;
                     sj += (v.x + v.y) + (v.z + v.w);
                 }
@@ -544,16 +570,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int j = 0; j < MI; ++j) red[(8 + wn) * BM + j * 16 + frow] = rsq[j];
             }
             __syncthreads();
-            f32x4 lw[4], lb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lw[i] = *reinterpret_cast<const f32x4*>(a.ln_w + nbase + i * 16);
-                lb[i] = *reinterpret_cast<const f32x4*>(a.ln_b + nbase + i * 16);
-            }
             mark();     // 2 (LNF): row statistics done, the store / reload phase starts
-            float* o32 = const_cast<float*>(res_tile(a.out32, cm0));
-            const float* rnext = res_tile(a.res, m0);                      // m0 is already the next tile's
-            f16* orow = a.out16 + (long)(cm0 + (lane >> 3)) * a.ldc + cn0 + wn * 64 + (lane & 7) * 8;
+            f16* o16 = a.out16 + x16t_off(cm0);
+            signed char* o8 = a.out8 + d8t_off(cm0);
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 if (j == JD) {
@@ -566,32 +585,23 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int w = 0; w < 8; ++w) tq += red[(8 + w) * BM + j * 16 + frow];
                 const float inv = a.ln_flavour == LN_STD ? 1.f / sqrtf(tq * (1.f / BN) + 1e-5f)
                                                          : 1.f / (sqrtf(tq * (1.f / (BN - 1))) + 1e-6f);
+                uint4 dq;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 y = acc[i][j] * inv * lw[i] + lb[i];
-                    *reinterpret_cast<f32x4*>(o32 + (j * 4 + i) * 256) = y;
-                    f16x4 hv = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
-                    *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
+                    const f32x4 y = acc[i][j] * inv * *reinterpret_cast<const f32x4*>(lnp + BN + ncol + i * 16) +
+                                    *reinterpret_cast<const f32x4*>(lnp + 2 * BN + ncol + i * 16);
+                    const f16x4 hv = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
+                    *reinterpret_cast<f16x4*>(o16 + j * 1024 + i * 256) = hv;
+                    const unsigned dw = (unsigned)(res_enc(y.x, hv[0]) & 0xff) | ((unsigned)(res_enc(y.y, hv[1]) & 0xff) << 8) |
+                                        ((unsigned)(res_enc(y.z, hv[2]) & 0xff) << 16) | ((unsigned)(res_enc(y.w, hv[3]) & 0xff) << 24);
+                    if (i == 0) dq.x = dw; else if (i == 1) dq.y = dw; else if (i == 2) dq.z = dw; else dq.w = dw;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
-                    *reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc) = o;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (nbid >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][j] = *reinterpret_cast<const f32x4*>(rnext + (j * 4 + i) * 256);
-                }
+                *reinterpret_cast<uint4*>(o8 + j * 1024) = dq;
+                if (nbid >= 0) load_stream(m0, j);                        // m0 is already the next tile's
             }
             mark();     // 3: epilogue issued
             if (nbid < 0) break;
-            // the loop-top barrier fences red[]/tsc against the next tile's k-tile 1 (staged after it)
+            // the loop-top barrier fences red[] / lnp[] against the next tile's k-tile 1 (staged after it)
             pending = counted_ok ? (MI - JD) * 10 : 0;
             continue;
         }
@@ -825,7 +835,7 @@ static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
 
 bool gemm_ln_fusable(const GemmArgs& a) {
     return a.Wl == nullptr && a.N == 512 && a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && !a.relu && !a.scale &&
-           a.res && a.res_mod == 0 && a.out32 && a.out16 && a.ldc == 512;
+           !a.res && !a.out32 && a.res16 && a.res8 && a.out16 && a.out8 && !a.a_tiled;
 }
 
 static bool g_big_tile = true;
@@ -1109,6 +1119,7 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
     }
     const bool w2 = a.Wl != nullptr;
     const bool narrow = a.N <= 64;
+    if (a.a_tiled && (conv || narrow || !g_use_glds || g_use_ring || a.K != 512 || a.M < 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
     if (conv) {
         if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
         if (g_use_glds && a.M >= 256 && a.g.C % 64 == 0) {
