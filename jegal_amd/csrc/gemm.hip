@@ -850,7 +850,8 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     // small problems (the JEGAL branch: M = B*T = 4800 tokens) would leave most CUs idle with 256-row tiles:
     // 128x128 tiles (32x64 wave tiles) give 4x the workgroups
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-    if (g_small_tile && tiles256 < 200) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
+    const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
+    if (g_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
     if constexpr (!W2) {
         if (g_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
         // N = 128 (conv2): 512x128 block tile, the whole 160 KiB of LDS -- the activation side dominates the
