@@ -652,7 +652,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
-                    *reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc) = o;
+                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
