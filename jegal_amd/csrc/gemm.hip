@@ -379,9 +379,12 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     auto asf = [](unsigned v) -> float { return __builtin_bit_cast(float, v); };
     auto load_stream = [&](int tm0, int j) __attribute__((always_inline)) {
         const f16* xp = a.res16 + x16t_off(tm0) + j * 1024;
-        const uint2 r0 = *reinterpret_cast<const uint2*>(xp), r1 = *reinterpret_cast<const uint2*>(xp + 256);
-        const uint2 r2 = *reinterpret_cast<const uint2*>(xp + 512), r3 = *reinterpret_cast<const uint2*>(xp + 768);
-        const uint4 dq = *reinterpret_cast<const uint4*>(a.res8 + d8t_off(tm0) + j * 1024);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // read-once stream: nontemporal, so it does not push the weights out of L2
+        const u32x2 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp)), r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 256));
+        const u32x2 r2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 512)), r3 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 768));
+        const u32x4 dq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res8 + d8t_off(tm0) + j * 1024));
         acc[0][j] = f32x4{asf(r0.x), asf(r0.y), asf(r3.x), asf(r3.y)};
         acc[1][j] = f32x4{asf(r1.x), asf(r1.y), 0.f, 0.f};
         acc[2][j] = f32x4{asf(r2.x), asf(r2.y), 0.f, 0.f};
