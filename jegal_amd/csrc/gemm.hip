@@ -320,7 +320,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             } else {
                 src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
+            // LNF, long K (linear2: 413 MB of hidden activations read once by one tile each): nontemporal (aux = 2) so
+            // the stream does not push the weights out of L2.  Measured: linear2+LN 282 -> 266 us; for out_proj (K = 512,
+            // its input was written by the attention kernel just before) the same hint costs 10 %.
+            if (LNF && a.K >= 1024) __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
         } else if (p < XI + WI) {
             const int i = p - XI;
             const bool kok = !CONV || (sk0 + wchunk[i] * 8 < a.K);
