@@ -205,7 +205,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MI = 16-row MFMA tiles per wave along m (4: 64x64 wave tile, 8: 128x64); WM x WN waves.
 //   <4,4,2>: 256x128 block tile (hi+lo weights fit two LDS stages);  <8,2,4>: 256x256 block tile for single-fp16
 //   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
-template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false>
+template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
     static_assert(!LNF || (WM == 1 && !W2), "fused LayerNorm needs a row-wide tile: all 8 waves side by side along n");
@@ -416,7 +416,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
         const int mb = cm0 + wm * (16 * MI) + frow;
-        constexpr bool SPREAD = LNF || CONV;      // measured: -16 % on the 128x512 LN kernel (K = 2048), +2-4 % on the 256x256 tiles, register spills on CONV
+        // spreading the DMA pieces over the MFMA schedule, measured: -16 % on the 128x512 LN kernel (K = 2048), -5 % on the
+        // conv variants, -3 % on the 256x256 Linear tile at K = 512 (SPR instance: qkv, linear1) but +3 % at K = 2048 there
+        constexpr bool SPREAD = LNF || CONV || SPR;
         constexpr bool PREFETCH_RES = MI <= 4;        // 128x64 wave tiles have no registers to spare for it
 
         f32x4 rs[4][PREFETCH_RES ? MI : 1];
@@ -778,13 +780,13 @@ static const f16* zero_page() {
     return z;
 }
 
-template <bool W2, bool CONV, int MI, int WM, int WN>
+template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false>
 static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr size_t lds = 2 * (size_t)(BM * 128 + BN * 128 * (W2 ? 2 : 1));
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV, MI, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -805,7 +807,7 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
         (void)hipStreamSynchronize(s);
         std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (g_stagger << 8), g_tl);
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (g_stagger << 8), g_tl);
     if (g_tl) dump_timeline(s, CONV ? "conv" : "linear");
     return hipGetLastError();
 }
@@ -860,7 +862,10 @@ static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
     const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
     if (g_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
     if constexpr (!W2) {
-        if (g_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
+        if (g_big_tile && a.N >= 256 && a.N % 256 == 0) {
+            if (!CONV && a.K <= 1024) return launch_glds_cfg<false, CONV, 8, 2, 4, !CONV>(a, s);       // short k loops: spread DMA issue
+            return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
+        }
         // N = 128 (conv2): 512x128 block tile, the whole 160 KiB of LDS -- the activation side dominates the
         // L2->LDS traffic there, a taller tile halves the weight re-reads per activation byte
         if (g_tall_tile && a.N == 128 && a.M >= 512 * 256) return launch_glds_cfg<false, CONV, 8, 4, 2>(a, s);
