@@ -48,7 +48,16 @@ int jg_set_stream(jg_handle* h, void* hip_stream);
 int jg_set_precision(jg_handle* h, int mode);
 /* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */
 int jg_set_chunk(jg_handle* h, int clips_per_chunk);
-/* tuning/debug switches: "conv1_direct" (1 default: fused u8 conv1 kernel; 0: stack + implicit GEMM) */
+/* tuning / A-B switches (all default to the fast setting; results stay within the parity tolerance either way):
+ *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel
+ *   "conv1_zero_skip" 1: all-zero input tiles (the face-mask rows) run only the bias slots (bit-identical)
+ *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
+ *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
+ *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
+ *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted":
+ *                     tile / pipeline choices of the LDS-DMA GEMM; "gemm_ring", "gemm_ring_cfg", "gemm_stagger":
+ *                     measured-slower variants kept for reference
+ *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug) */
 int jg_set_option(jg_handle* h, const char* name, int value);
 int jg_sync(jg_handle* h);
 
