@@ -807,7 +807,12 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
         (void)hipStreamSynchronize(s);
         std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (g_stagger << 8), g_tl);
+    // De-phasing the workgroups (4 phases, 2 us apart; the last phase falls on the workgroups that run one tile fewer):
+    // once the outputs were nontemporal the epilogues became HBM-write-burst bound (every CU stores its 128 KB at the
+    // same moment) and spreading them pays: qkv 157 -> 146 us.  Only for long plain GEMMs (>= 4 rounds); the LN-fused
+    // and conv kernels and short launches measured neutral or slower.  Option gemm_stagger: ticks of 10 ns, -1 = off.
+    const int stagger = g_stagger < 0 ? 0 : g_stagger > 0 ? g_stagger : (!CONV && tiles >= 4 * num_cu ? 200 : 0);
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (stagger << 8), g_tl);
     if (g_tl) dump_timeline(s, CONV ? "conv" : "linear");
     return hipGetLastError();
 }
@@ -837,7 +842,7 @@ static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
         (void)hipStreamSynchronize(s);
         std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, g_counted | (g_stagger << 8), g_tl);
+    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, g_counted | ((g_stagger > 0 ? g_stagger : 0) << 8), g_tl);
     if (g_tl) dump_timeline(s, "linear+LN");
     return hipGetLastError();
 }
