@@ -219,7 +219,9 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const int pcg = (ltid >> 4) & 7, ppw = ltid & 15;                         // part A: 2 x 8 x 16 threads
         const int prow = __builtin_amdgcn_readfirstlane(ltid >> 7);               // wave-uniform: waves 4,5 / 6,7
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
-        auto pool = [&](const Pos& q, int t) {
+        // fastz: tile t AND the carry above it come from all-zero input tiles, so every conv value involved is the same
+        // per-channel constant relu(bias): one LDS read instead of the 3x3 window
+        auto pool = [&](const Pos& q, int t, bool fastz) {
             const int rt = q.rt;
             const int nf = (int)((unsigned)q.strip / 5u);
             const int j = q.strip - nf * 5;
@@ -232,17 +234,23 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             // three conv columns of the pooling window; for ppw == 15 column 32 belongs to strip j+1
             // (edge fix-up), so column 31 is simply read twice (max is idempotent) -- no divergent branch
             const int c0 = 2 * ppw, c1 = c0 + 1, c2 = c0 + 2 < 32 ? c0 + 2 : 31;
-            const f16x8 q2 = at(cbuf, 2, ccg, ccol), q3 = at(cbuf, 3, ccg, ccol);
-            f16x8 m;
-            if (prow == 0) {            // pooled row 2rt-1: carry (conv rows 4rt-2, 4rt-1) and R0
-                const f16x8 a0 = at(cin, 0, pcg, c0), a1 = at(cin, 0, pcg, c1), a2 = at(cin, 0, pcg, c2);
-                const f16x8 b0 = at(cbuf, 0, pcg, c0), b1 = at(cbuf, 0, pcg, c1), b2 = at(cbuf, 0, pcg, c2);
-                m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(b1, b2));
-            } else {                    // pooled row 2rt: R0, R1, R2
-                const f16x8 a0 = at(cbuf, 0, pcg, c0), a1 = at(cbuf, 0, pcg, c1), a2 = at(cbuf, 0, pcg, c2);
-                const f16x8 b0 = at(cbuf, 1, pcg, c0), b1 = at(cbuf, 1, pcg, c1), b2 = at(cbuf, 1, pcg, c2);
-                const f16x8 d0 = at(cbuf, 2, pcg, c0), d1 = at(cbuf, 2, pcg, c1), d2 = at(cbuf, 2, pcg, c2);
-                m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(max8(b1, b2), max8(max8(d0, d1), d2)));
+            f16x8 m, cnext;
+            if (fastz) {
+                m = at(cbuf, 0, pcg, 0);
+                cnext = at(cbuf, 0, ccg, 0);
+            } else {
+                const f16x8 q2 = at(cbuf, 2, ccg, ccol), q3 = at(cbuf, 3, ccg, ccol);
+                cnext = max8(q2, q3);
+                if (prow == 0) {            // pooled row 2rt-1: carry (conv rows 4rt-2, 4rt-1) and R0
+                    const f16x8 a0 = at(cin, 0, pcg, c0), a1 = at(cin, 0, pcg, c1), a2 = at(cin, 0, pcg, c2);
+                    const f16x8 b0 = at(cbuf, 0, pcg, c0), b1 = at(cbuf, 0, pcg, c1), b2 = at(cbuf, 0, pcg, c2);
+                    m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(b1, b2));
+                } else {                    // pooled row 2rt: R0, R1, R2
+                    const f16x8 a0 = at(cbuf, 0, pcg, c0), a1 = at(cbuf, 0, pcg, c1), a2 = at(cbuf, 0, pcg, c2);
+                    const f16x8 b0 = at(cbuf, 1, pcg, c0), b1 = at(cbuf, 1, pcg, c1), b2 = at(cbuf, 1, pcg, c2);
+                    const f16x8 d0 = at(cbuf, 2, pcg, c0), d1 = at(cbuf, 2, pcg, c1), d2 = at(cbuf, 2, pcg, c2);
+                    m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(max8(b1, b2), max8(max8(d0, d1), d2)));
+                }
             }
             const int ph = 2 * rt - 1 + prow;
             const int pw = 16 * j + ppw;
@@ -250,12 +258,13 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 __builtin_nontemporal_store(m, reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8));   // streamed: keep the frames in L2
             if (ph >= 0 && j > 0 && ppw == 0) {     // export conv column 0 (vertically pooled) for strip j-1's last pooled column
                 f16x8 e;
-                if (prow == 0) e = max8(at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
+                if (fastz) e = m;
+                else if (prow == 0) e = max8(at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
                 else e = max8(max8(at(cbuf, 0, pcg, 0), at(cbuf, 1, pcg, 0)), at(cbuf, 2, pcg, 0));
                 *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = e;
             }
             // carry for the next tile of the strip
-            *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = max8(q2, q3);
+            *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = cnext;
         };
 
         if (a.dbg & 1) {
@@ -298,32 +307,42 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         //   (2) reload the same registers with tile t+3,
         //   (3) pool tile t-1 (its stores go last).
         // Two register sets, so the loop is unrolled by two (a runtime-selected set would be a phi again).
+        // zero status (flags, see cvt_write) of the tiles t-1 and t-2: final once the barrier of their iteration is passed
+        bool z1 = false, z2 = false;
+        auto tile_is_zero = [&](int tt) -> bool {
+            const int4 fl = *reinterpret_cast<const int4*>(smem + OFF_INIT + (tt & 1) * 16);
+            return __builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) == 0;
+        };
         int t = 0;
         while (t < ntl) {
             mark();
             __syncthreads();
             mark();
+            const bool zc0 = tile_is_zero(t);          // before cvt_write reuses the other slot; this slot is rewritten at t+1
             if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
             issue(qi, RB);
             next_i();
             mark();
-            if (t > 0 && !(a.dbg & 4)) { pool(qp, t - 1); advance(qp); }
+            if (t > 0 && !(a.dbg & 4)) { pool(qp, t - 1, z1 && (z2 || qp.rt == 0)); advance(qp); }
+            z2 = z1; z1 = zc0;
             ++t;
             if (t >= ntl) break;
             mark();
             __syncthreads();
             mark();
+            const bool zc1 = tile_is_zero(t);
             if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
             issue(qi, RA);
             next_i();
             mark();
-            if (!(a.dbg & 4)) { pool(qp, t - 1); advance(qp); }
+            if (!(a.dbg & 4)) { pool(qp, t - 1, z1 && (z2 || qp.rt == 0)); advance(qp); }
+            z2 = z1; z1 = zc1;
             ++t;
         }
         __syncthreads();                       // the MFMA waves have finished the last tile
-        if (ntl > 0 && !(a.dbg & 4)) pool(qp, ntl - 1);
+        if (ntl > 0 && !(a.dbg & 4)) pool(qp, ntl - 1, z1 && (z2 || qp.rt == 0));
         return;
     }
 
