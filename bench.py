@@ -4,99 +4,180 @@ Workload (BASELINE.json configs[1]): per GPU a batch of 32 s
 150 frames x 270x480x3 uint8 (face rows zeroed), resident in HBM; one step = frames -> GestSync
 (conv stack de-duplicated over windows, transformer, ff_vid, mean) -> JEGAL gesture encoder ->
 align MLP -> L2-normalise -> (32,150,512).  Weak scaling: every rank has its own 32 clips, no
-collective on the data path.
+collective on the data path.  After the timed loop every rank takes part in ONE config-4 retrieval
+evaluation (seed-1237 gallery of 10 000 clips, queries sharded ceil(N/G) per rank, gallery assembled by an
+all-gather: RCCL over xGMI) whose R@K / MR must equal the single-rank result.
 
-Usage: python bench.py [--gpus N --steps K --warmup W]      (N>1: launched by torch.distributed.run)
+Usage: python bench.py [--gpus N --steps K --warmup W]
+  N > 1 without a torchrun environment: this process starts N fresh rank processes itself (it makes no GPU
+  call before or after doing so) and relays rank 0's JSON line.  Under `python -m torch.distributed.run
+  --nproc-per-node N bench.py --gpus N ...` the ranks come from the environment; WORLD_SIZE != N is an error.
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from jegal_amd import synth                                   # noqa: E402
-from jegal_amd import dist as jdist                           # noqa: E402
-
 CLIPS, FRAMES = 32, 150
-# conv1 algorithmic FLOPs: SURVEY 8d counts 170 window-de-duplicated positions (222.4 GFLOP/clip); the
-# kernel also skips the 16 duplicated edge positions, so utilisation is priced on the 154 positions it
-# really evaluates: 154 x 13904 px x 64 ch x 735 taps x 2 = 201.5 GFLOP/clip (never on padded K/tiles).
-CONV1_GFLOP_PER_CLIP = 154 * 13904 * 64 * 735 * 2 / 1e9
-# The synthetic clips carry the reference's face mask (rows 0..109 zero, SURVEY 8d config 2); conv1 detects all-zero
-# input tiles at run time and runs only their bias slots.  8 of the 22 row tiles of every strip (input rows
-# 12*rt .. 12*rt+15 <= 109) are such tiles: the roofline prices the kernel on the FLOPs it executes, and the same
-# launch is timed once more on frames without any zero row (`dense_input`).
+# ---- algorithmic work per clip (SURVEY 8d; never padded K or tile waste).  SURVEY counts 170 window-de-duplicated
+# conv positions per 150-frame clip; the engine evaluates the 154 DISTINCT ones (positions 0..8 and T+11..T+19 of the
+# edge-padded clip see five copies of one frame), and every utilisation figure below is priced on those 154.
+POS_SURVEY, POS_EXEC = 170, 154
+CONV1_GFLOP_PER_CLIP = POS_EXEC * 13904 * 64 * 735 * 2 / 1e9                       # 201.5
+CONV_REST_GFLOP_PER_CLIP = (333.8 - 222.4) * POS_EXEC / POS_SURVEY                 # conv2..fc6: 100.9
+LINEAR_GFLOP_PER_CLIP = 131.1      # GestSync transformer + ff_vid (124.7) + JEGAL gesture + align (6.4)
+# The synthetic clips carry the reference's face mask (rows 0..109 zero, SURVEY 8d config 2).  conv1 skips all-zero
+# input tiles: 8 of the 22 row tiles of every strip (input rows 12*rt .. 12*rt+15 <= 109).  The roofline prices the
+# kernel on the FLOPs it EXECUTES; the same launch is timed once more on frames without a zero row (`dense_input`).
 CONV1_EXECUTED_TILE_FRACTION = 14.0 / 22.0
-TOTAL_GFLOP_PER_CLIP = 464.9       # SURVEY 8d total, v-only
-LINEAR_GFLOP_PER_CLIP = 131.1      # SURVEY 8d: GestSync transformer + ff_vid (124.7) + JEGAL gesture + align (6.4)
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 (MI355X_MICROARCH.md)
-# HBM traffic of one conv1_direct_kernel launch (32 clips) from separate rocprofv3 --pmc passes (profiles/r1d_pmc_hbm_traffic.csv
-# + profiles/README.md): FETCH_SIZE 2.2e6 KB, WRITE_SIZE 2.17e6 KB.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
-# gfx950 (128-B requests tallied at 64 B); that rule is calibrated for 16-B/lane streaming reads, the frame loads here are
-# 12 B/lane, so the doubled figure is an upper bound (Infinity-Cache hits are counted as well).
-CONV1_TRAFFIC_BYTES_PER_32CLIPS = (2 * 2.2e6 + 2.17e6) * 1024
+HBM_PEAK_GBS = 8000.0
+# algorithmic HBM bytes of the conv stack per clip (SURVEY 8d, uint8 input): 154 x 5... the u8 frames are read once
+# (150 x 388.8 KB = 58.3 MB), every inter-layer activation is written once and read once in fp16.
+CONV_ALGO_BYTES_PER_CLIP = (FRAMES * 270 * 480 * 3 +
+                            2 * 2 * POS_EXEC * (43 * 78 * 64 + 20 * 37 * 128 + 10 * 19 * 256 + 2 * 10 * 10 * 256 + 4 * 4 * 256) +
+                            4 * POS_EXEC * 512)
+CONV1_ALGO_BYTES_PER_CLIP = FRAMES * 270 * 480 * 3 + 2 * POS_EXEC * 43 * 78 * 64
 
 
-def cpu_baseline(clip_u8, n_windows=150):
-    """The reference's algorithm (naive per-window conv stack, fp32, all host cores) via the oracle
-    port, on a bounded sample: the first `n_windows` windows of one 150-frame clip plus the JEGAL
-    gesture branch; extrapolated to a whole clip."""
+def load_traffic():
+    """Per-launch HBM traffic of the dominant kernel from the committed counter passes (profiles/r2_pmc_summary.json,
+    written by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
+    command).  None when the summary is absent."""
+    p = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
+    if not os.path.exists(p):
+        return None, "no committed counter summary (profiles/r2_pmc_summary.json)"
+    d = json.load(open(p))
+    k = d.get("conv1_direct_kernel")
+    if not k:
+        return None, "conv1_direct_kernel missing from profiles/r2_pmc_summary.json"
+    return k["hbm_bytes_per_launch"], k.get("note", "")
+
+
+def cpu_baseline(clips_u8, n_windows=96):
+    """The reference's algorithm via the oracle port on the host cores, bounded sample: the first `n_windows` windows
+    of each of TWO seed-1234 clips through the naive per-window fp32 conv stack (batches of 48 windows, as
+    inference_embs.py:499) + the JEGAL gesture branch, extrapolated to whole clips; next to it the window-de-duplicated
+    variant of the same port on the same two clips (whole clips)."""
+    import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import jegal_oracle as O
+    from jegal_amd import synth
     cores = min(os.cpu_count() or 1, 64)     # more threads than this slows the small JEGAL matmuls down
     torch.set_num_threads(cores)
     gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
     jsd = O.tensors(synth.jegal_state_dict())
-    f01 = torch.from_numpy(clip_u8.astype(np.float32) / np.float32(255.0))
-    padded = O.pad_clip(f01)
-    vol = padded.permute(3, 0, 1, 2)
+    t_win = t_j = t_dd = 0.0
+    n_clips = len(clips_u8)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        parts = []
-        for s0 in range(0, n_windows, 48):                       # the reference's batches of 48 windows
-            xs = torch.stack([vol[:, i:i + 25] for i in range(s0, min(n_windows, s0 + 48))])
-            parts.append(O.gestsync_forward_vid(gsd, xs).mean(-1))
-        feats = torch.cat(parts)
-        t_win = time.perf_counter() - t0
-        vis = feats[None].repeat(1, FRAMES // n_windows + 1, 1)[:, :FRAMES]
-        t0 = time.perf_counter()
-        O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=vis, visual_mask=torch.ones(1, FRAMES)))
-        t_j = time.perf_counter() - t0
-    per_clip = t_win * FRAMES / n_windows + t_j
+        for clip in clips_u8:
+            f01 = torch.from_numpy(clip.astype(np.float32) / np.float32(255.0))
+            vol = O.pad_clip(f01).permute(3, 0, 1, 2)
+            t0 = time.perf_counter()
+            parts = []
+            for s0 in range(0, n_windows, 48):
+                xs = torch.stack([vol[:, i:i + 25] for i in range(s0, min(n_windows, s0 + 48))])
+                parts.append(O.gestsync_forward_vid(gsd, xs).mean(-1))
+            feats = torch.cat(parts)
+            t_win += time.perf_counter() - t0
+            vis = feats[None].repeat(1, FRAMES // n_windows + 1, 1)[:, :FRAMES]
+            t0 = time.perf_counter()
+            O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=vis, visual_mask=torch.ones(1, FRAMES)))
+            t_j += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            fd = O.gestsync_clip_feats(gsd, f01)
+            O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=fd[None], visual_mask=torch.ones(1, FRAMES)))
+            t_dd += time.perf_counter() - t0
+    per_clip = (t_win * FRAMES / n_windows + t_j) / n_clips
     return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{n_windows} of 150 windows of one seed-1234 clip through the reference algorithm (naive per-window "
-                      f"fp32 conv stack, batches of 48: {t_win:.1f} s) + JEGAL gesture branch ({t_j * 1e3:.0f} ms)"}
+            "sample": f"{n_windows} of 150 windows of each of {n_clips} seed-1234 clips through the reference algorithm (naive per-window "
+                      f"fp32 conv stack, batches of 48: {t_win:.1f} s) + JEGAL gesture branch ({t_j * 1e3:.0f} ms), extrapolated to whole clips",
+            "dedup_variant": {"value": n_clips / t_dd, "unit": "clips/s",
+                              "what": f"same port with the conv stack evaluated once per padded-clip position (exact), {n_clips} whole clips in {t_dd:.1f} s"}}
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside torchrun: start N fresh rank processes (one per GPU).  This parent never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        sys.exit(1)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default 150 ~ 2 s of sustained work)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
     ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing aid: allow more ranks than GPUs (ranks share devices round-robin; forces backend gloo; flagged in the output)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tuning experiments)")
     args = ap.parse_args()
 
-    jdist.init_from_env("nccl")
-    rank, world = jdist.rank(), jdist.world_size()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return launch_ranks(args, sys.argv[1:])
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}")
+
+    import numpy as np
+    import torch
+    from jegal_amd import synth
+    from jegal_amd import dist as jdist
+
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible (jegal_amd has no CPU path)")
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if args.gpus > ndev and not args.oversubscribe:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} device(s) visible (use --oversubscribe only to test the launcher)")
+    oversub = args.gpus > ndev
+    backend = "gloo" if oversub else args.backend
+    local_dev = local % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    if args.gpus > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend=backend)
+    rank, world = jdist.rank(), jdist.world_size()
+    assert world == args.gpus, (world, args.gpus)
 
     from jegal_amd._lib import Engine
     from jegal_amd.gestsync import GestSync
     from jegal_amd.jegal import JEGAL
-    eng = Engine(local, precision=args.precision)
+    eng = Engine(local_dev, precision=args.precision)
     eng.set_chunk(args.chunk)
     for o in args.opt:
         k, v = o.split("=")
@@ -108,56 +189,103 @@ def main():
     frames = torch.from_numpy(frames_host).to(dev)
     out = torch.empty((args.clips, FRAMES, 512), dtype=torch.float32, device=dev)
 
+    def sync_all():
+        torch.cuda.synchronize()
+        jdist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_loop(n):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.extract_gesture(frames, out)
+        sync_all()
+        tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        jdist.all_reduce_max(tmax)
+        return float(tmax.item())
+
     for _ in range(args.warmup):
         eng.extract_gesture(frames, out)
-    torch.cuda.synchronize()
-    jdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.extract_gesture(frames, out)
-    torch.cuda.synchronize()
-    jdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = timed_loop(args.steps)
     assert torch.isfinite(out).all(), "non-finite embeddings"
 
-    # per-kernel timing of the dominant kernel (conv1) with HIP events on the launch stream
+    # ---- per-kernel timing with HIP events on the launch stream (dominant kernel: conv1)
     eng.profile_reset()
     eng.profile(True)
-    eng.extract_gesture(frames, out)
+    nprof = 3
+    for _ in range(nprof):
+        eng.extract_gesture(frames, out)
     prof = eng.profile_get()
     eng.profile(False)
     c1_ms, c1_n = prof["conv1"]
-    # the same step on frames with no zero rows (timing only): every conv1 tile is computed
-    dense = torch.randint(0, 256, frames.shape, dtype=torch.uint8, device=dev)
-    eng.extract_gesture(dense, out)
-    eng.profile_reset()
-    eng.profile(True)
-    torch.cuda.synchronize()
-    td0 = time.perf_counter()
-    eng.extract_gesture(dense, out)
-    torch.cuda.synchronize()
-    dense_dt = time.perf_counter() - td0
-    dprof = eng.profile_get()
-    eng.profile(False)
-    del dense
-    d1_ms, d1_n = dprof["conv1"]
+
+    extras = {}
+    if not args.no_extras:
+        # the same step on frames with no zero rows (timing only): every conv1 tile is computed
+        dense = torch.randint(0, 256, frames.shape, dtype=torch.uint8, device=dev)
+        eng.extract_gesture(dense, out)
+        eng.profile_reset()
+        eng.profile(True)
+        for _ in range(nprof):
+            eng.extract_gesture(dense, out)
+        dprof = eng.profile_get()
+        eng.profile(False)
+        del dense
+        extras["dense_ms"], extras["dense_n"] = dprof["conv1"]
+        # sustained rate: whatever K the driver asked for, also run ~2.5 s of back-to-back steps (clocks settle)
+        per = dt / max(args.steps, 1)
+        n_sus = max(args.steps, int(2.5 / max(per, 1e-4)))
+        extras["sustained_steps"], extras["sustained_s"] = n_sus, timed_loop(n_sus)
+        # config 4: sharded retrieval evaluation with the gallery all-gather
+        from jegal_amd import metrics as M
+        N = 10000
+        ge, ce = synth.planted_retrieval(1237, N)
+        lo, hi = jdist.shard_range(N)
+        q_dev, g_dev = torch.from_numpy(ce[lo:hi]).to(dev), torch.from_numpy(ge[lo:hi]).to(dev)
+        M.retrieval_metrics(q_dev, g_dev, engine=eng)                    # warm-up (RCCL connection set-up)
+        sync_all()
+        t0 = time.perf_counter()
+        m_sharded = M.retrieval_metrics(q_dev, g_dev, engine=eng)
+        sync_all()
+        tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        jdist.all_reduce_max(tm)
+        extras["retrieval"] = {"n": N, "ms": float(tm.item()) * 1e3, "metrics": m_sharded}
+        if rank == 0:
+            r_all, t_all = eng.sim_rank(eng.l2norm(torch.from_numpy(ce).to(dev)), eng.l2norm(torch.from_numpy(ge).to(dev)))
+            m_single = M.metrics_from_ranks(r_all.cpu().numpy(), t_all.cpu().numpy())
+            assert m_single == m_sharded, ("sharded retrieval metrics differ from the single-rank result", m_single, m_sharded)
+            extras["retrieval"]["equals_single_rank"] = True
+            # PCIe-inclusive rate (host-resident clips -> pinned buffers -> H2D under compute -> D2H), never `value`
+            if world == 1:
+                from jegal_amd.extract import GestureStreamer
+                st = GestureStreamer(eng, args.clips, FRAMES)
+                for s_ in range(2):
+                    st.h_in[s_].numpy()[:] = frames_host
+                nb = 6
+                for _ in st.run_filled(lambda buf, k: args.clips if k < 2 else 0):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                got = 0
+                for _, emb in st.run_filled(lambda buf, k: args.clips if k < nb else 0):
+                    got += emb.shape[0]
+                extras["pcie_clips_per_s"] = got / (time.perf_counter() - t0)
+                del st
+    jdist.barrier()
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
         value = clips_total / dt
         c1_avg_s = (c1_ms / max(c1_n, 1)) * 1e-3
-        clips_per_launch = args.clips / max(c1_n, 1)
+        clips_per_launch = args.clips * nprof / max(c1_n, 1)
         zskip = not any(o.replace(" ", "") == "conv1_zero_skip=0" for o in args.opt)
         exec_frac = CONV1_EXECUTED_TILE_FRACTION if zskip else 1.0
         achieved = CONV1_GFLOP_PER_CLIP * exec_frac * clips_per_launch / c1_avg_s / 1e3 if c1_avg_s > 0 else 0.0
-        d1_avg_s = (d1_ms / max(d1_n, 1)) * 1e-3
-        dense_achieved = CONV1_GFLOP_PER_CLIP * clips_per_launch / d1_avg_s / 1e3 if d1_avg_s > 0 else 0.0
+        traffic, traffic_note = load_traffic()
+        exec_gflop_clip = CONV1_GFLOP_PER_CLIP * exec_frac + CONV_REST_GFLOP_PER_CLIP + LINEAR_GFLOP_PER_CLIP
+        stage = {k: v[0] / nprof for k, v in prof.items()}
+        conv_ms = stage["conv1"] + stage["maxpool"] + stage["conv2-fc6+audio_cnn"] + stage["stack_frames"]
+        lin_ms = stage["gemm"] + stage["attention"] + stage["layernorm"]
         res = {
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -167,33 +295,53 @@ def main():
                                    "uint8 150x270x480x3 clips resident in HBM, seeded synthetic weights",
                        "clips_per_gpu": args.clips, "frames": FRAMES, "precision_mode": args.precision, "chunk": args.chunk,
                        "conv1_zero_tile_skip": zskip,
-                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU, 154 distinct positions/clip)", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "traffic": CONV1_TRAFFIC_BYTES_PER_32CLIPS * clips_per_launch / 32.0,
-                         "traffic_note": "PMC FETCH_SIZE*2+WRITE_SIZE from profiles/r1d_pmc_hbm_traffic.csv (separate --pmc passes, not re-measured in this run; upper bound, includes Infinity-Cache hits); algorithmic 1.87 GB in + 2.18 GB out per 32 clips",
-                         "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n,
+                       "parallelism": f"clip-sharded x{world}, no data-path collective" + (" (OVERSUBSCRIBED: ranks share GPUs, gloo)" if oversub else "")},
+            "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU+maxpool, 154 distinct positions/clip)",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": traffic * clips_per_launch / 32.0 if traffic else None, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch,
+                         "hbm_frac_of_peak": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch / c1_avg_s / 1e9 / HBM_PEAK_GBS if c1_avg_s > 0 else None,
+                         "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n / nprof,
                          "executed_tile_fraction": exec_frac,
-                         "flops_note": "achieved = executed FLOPs / launch time: all-zero input tiles (the face-mask rows, 8 of 22 row tiles of the "
-                                       "synthetic clips) run only the bias slots and are not counted",
-                         "dense_input": {"what": "same launch on uniform-noise frames without zero rows (timing only): every tile computed",
-                                         "launch_ms": d1_avg_s * 1e3, "achieved": dense_achieved, "frac": dense_achieved / MFMA_PEAK_TFLOPS,
-                                         "step_ms_with_event_overhead": dense_dt * 1e3},
-                         "whole_path_frac": value / world * (TOTAL_GFLOP_PER_CLIP - CONV1_GFLOP_PER_CLIP * (1.0 - exec_frac)) / 1e3 / MFMA_PEAK_TFLOPS},
-            # second-largest consumer: all Linear-layer GEMM launches of a step taken together (algorithmic FLOPs only:
+                         "flops_note": "achieved = EXECUTED algorithmic FLOPs / launch time (HIP events on the launch stream, mean of "
+                                       f"{c1_n} launches): all-zero input tiles (the face-mask rows, 8 of 22 row tiles of the synthetic clips) are not counted",
+                         # whole path, priced consistently on executed work (154 positions, executed conv1 tiles)
+                         "whole_path": {"executed_gflop_per_clip": exec_gflop_clip,
+                                        "frac": value / world * exec_gflop_clip / 1e3 / MFMA_PEAK_TFLOPS}},
+            # SURVEY 8d asks for BOTH fractions on the conv extractor: algorithmic HBM bytes of the whole conv stack / its time
+            "roofline_conv_stack": {"bound": "mfma", "ms_per_step": conv_ms,
+                                    "mfma_frac": (CONV1_GFLOP_PER_CLIP * exec_frac + CONV_REST_GFLOP_PER_CLIP) * args.clips / max(conv_ms, 1e-9) / MFMA_PEAK_TFLOPS,
+                                    "algorithmic_bytes_per_step": CONV_ALGO_BYTES_PER_CLIP * args.clips,
+                                    "achieved_gbs": CONV_ALGO_BYTES_PER_CLIP * args.clips / max(conv_ms, 1e-9) / 1e6,
+                                    "hbm_frac": CONV_ALGO_BYTES_PER_CLIP * args.clips / max(conv_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                    "note": "the conv stack is MFMA-bound (620 FLOP/B): the HBM fraction is reported because north_star asks for it, not because it is the roof"},
+            # attention + MLP blocks: every Linear GEMM, attention and LayerNorm launch of a step (algorithmic FLOPs only:
             # the hi+lo weight split of precision mode 1 is NOT counted as work)
-            "roofline_linear_gemms": {"bound": "mfma", "kernel": "gemm_glds_kernel (all Linear layers of one step)",
-                                      "achieved": LINEAR_GFLOP_PER_CLIP * args.clips / max(prof["gemm"][0], 1e-9), "peak": MFMA_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": LINEAR_GFLOP_PER_CLIP * args.clips / max(prof["gemm"][0], 1e-9) / MFMA_PEAK_TFLOPS,
-                                      "ms_per_step": prof["gemm"][0], "launches_per_step": prof["gemm"][1]},
-            "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
+            "roofline_linear_gemms": {"bound": "mfma", "kernel": "all Linear GEMM + attention + LayerNorm launches of one step",
+                                      "achieved": LINEAR_GFLOP_PER_CLIP * args.clips / max(lin_ms, 1e-9), "peak": MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": LINEAR_GFLOP_PER_CLIP * args.clips / max(lin_ms, 1e-9) / MFMA_PEAK_TFLOPS,
+                                      "ms_per_step": lin_ms, "gemm_only_ms": stage["gemm"], "launches_per_step": prof["gemm"][1] / nprof},
+            "stage_ms_per_step": {k: round(v, 3) for k, v in stage.items()},
         }
+        if "dense_ms" in extras:
+            d1 = extras["dense_ms"] / max(extras["dense_n"], 1) * 1e-3
+            da = CONV1_GFLOP_PER_CLIP * clips_per_launch / d1 / 1e3 if d1 > 0 else 0.0
+            res["roofline"]["dense_input"] = {"what": "same launch on uniform-noise frames without zero rows (timing only): every tile computed",
+                                              "launch_ms": d1 * 1e3, "achieved": da, "frac": da / MFMA_PEAK_TFLOPS}
+            res["sustained"] = {"steps": extras["sustained_steps"], "seconds": extras["sustained_s"],
+                                "value": args.clips * world * extras["sustained_steps"] / extras["sustained_s"], "unit": "clips/s"}
+            res["retrieval_config4"] = extras["retrieval"]
+            if "pcie_clips_per_s" in extras:
+                res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",
+                                         "what": "host-resident clips -> pinned buffers -> H2D under compute -> embeddings back on the host (GestureStreamer); never `value`"}
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(frames_host[0])
+            res["cpu_baseline"] = cpu_baseline(frames_host[:2])
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
     jdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

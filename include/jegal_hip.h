@@ -48,15 +48,14 @@ int jg_set_stream(jg_handle* h, void* hip_stream);
 int jg_set_precision(jg_handle* h, int mode);
 /* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */
 int jg_set_chunk(jg_handle* h, int clips_per_chunk);
-/* tuning / A-B switches (all default to the fast setting; results stay within the parity tolerance either way):
+/* tuning / A-B switches, per handle (all default to the fast setting; results stay within the parity tolerance either way):
  *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel
  *   "conv1_zero_skip" 1: all-zero input tiles (the face-mask rows) run only the bias slots (bit-identical)
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
  *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
- *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted":
- *                     tile / pipeline choices of the LDS-DMA GEMM; "gemm_ring", "gemm_ring_cfg", "gemm_stagger":
- *                     measured-slower variants kept for reference
+ *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
+ *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_parity.py flips every one of them)
  *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug) */
 int jg_set_option(jg_handle* h, const char* name, int value);
 int jg_sync(jg_handle* h);
@@ -126,7 +125,9 @@ int jg_pool_mean(jg_handle* h, const float* x, const int32_t* offsets, int n, in
 /* evaluate_retrieval.py:38-65 on already-normalised rows: rank/ties of the diagonal per local row */
 int jg_sim_rank(jg_handle* h, const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
                 int32_t* rank, int32_t* ties);
-/* evaluate_spotting.py:39-82: per clip first-argmax frame and its softmax score for word `target` */
+/* evaluate_spotting.py:39-82: per clip first-argmax frame and its softmax score for word `target`.
+ * Limits per clip: <= 1024 words, <= 8192 frames, 0 <= target < words.  The offsets are device arrays (no host sync to
+ * validate them): a clip outside the limits gets pred = -1 and score = NaN instead of a result. */
 int jg_spot(jg_handle* h, const float* gesture, const float* content, const int32_t* g_offsets, const int32_t* c_offsets,
             const int32_t* target, int n_clips, int D, float temp, int32_t* pred, float* score);
 /* evaluate_asd.py:43-51,94-100: pred (n,3) = argmax over the first 2/4/6 candidates */

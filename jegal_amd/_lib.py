@@ -182,26 +182,41 @@ class Engine:
         if frames is None:
             self._ck(self.lib.jg_calibrate_gesture(self.h, None, JG_U8, 0, 0))
             return
+        frames, code, B, T = self._frames_arg(frames)
+        self._ck(self.lib.jg_calibrate_gesture(self.h, _ptr(frames), code, B, T))
+
+    def _frames_arg(self, frames):
+        """Validate a clip batch and put it on this engine's device: (B,T,270,480,3) uint8 (decoded video) or
+        floating point in [0,1].  Returns (contiguous device tensor, dtype code, B, T).  A wrong shape would hand the
+        conv1 kernel a raw pointer it reads 270x480x3 bytes per frame from, so it is rejected here."""
+        if not isinstance(frames, torch.Tensor):
+            frames = torch.as_tensor(frames)
+        if frames.dim() != 5 or tuple(frames.shape[2:]) != (270, 480, 3):
+            raise ValueError(f"frames must be (B,T,270,480,3), got {tuple(frames.shape)}")
+        if frames.shape[0] == 0 or frames.shape[1] == 0:
+            raise ValueError("frames must hold at least one clip of at least one frame")
         frames = frames.to(self.device)
-        code = JG_U8 if frames.dtype == torch.uint8 else JG_F32
-        if code == JG_F32:
-            frames = frames.to(torch.float32)
-        frames = frames.contiguous()
-        self._ck(self.lib.jg_calibrate_gesture(self.h, _ptr(frames), code, frames.shape[0], frames.shape[1]))
+        if frames.dtype == torch.uint8:
+            code = JG_U8
+        elif frames.dtype.is_floating_point:
+            frames, code = frames.to(torch.float32), JG_F32
+        else:
+            raise ValueError(f"frames must be uint8 or floating point, got {frames.dtype}")
+        return frames.contiguous(), code, frames.shape[0], frames.shape[1]
+
+    def _out_arg(self, out, shape):
+        if out is None:
+            return torch.empty(shape, dtype=torch.float32, device=self.device)
+        if (not isinstance(out, torch.Tensor) or out.device != self.device or out.dtype != torch.float32
+                or tuple(out.shape) != tuple(shape) or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {tuple(shape)} on {self.device}")
+        return out
 
     # ---- GestSync
     def gestsync_clip(self, frames):
         """frames (B,T,270,480,3) uint8 or float32 cuda tensor -> (B,T,1024) fp32."""
         self._bind_stream()
-        frames = frames.to(self.device)
-        if frames.dtype == torch.uint8:
-            code = JG_U8
-        else:
-            frames, code = frames.to(torch.float32), JG_F32
-        frames = frames.contiguous()
-        B, T, H, W, C = frames.shape
-        if (H, W, C) != (270, 480, 3):
-            raise ValueError(f"frames must be (B,T,270,480,3), got {tuple(frames.shape)}")
+        frames, code, B, T = self._frames_arg(frames)
         out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
         return out
@@ -235,14 +250,10 @@ class Engine:
     def extract_gesture(self, frames, out=None):
         """frames -> unit-norm gesture embedding (B,T,512), one library call."""
         self._bind_stream()
-        if frames.dtype == torch.uint8:
-            code = JG_U8
-        else:
-            frames, code = frames.to(torch.float32), JG_F32
-        frames = frames.contiguous()
-        B, T = frames.shape[:2]
-        if out is None:
-            out = torch.empty((B, T, 512), dtype=torch.float32, device=self.device)
+        frames, code, B, T = self._frames_arg(frames)
+        if T > 500:
+            raise ValueError("clips are limited to 500 frames (JEGAL's positional table, modules.py:136)")
+        out = self._out_arg(out, (B, T, 512))
         self._ck(self.lib.jg_extract_gesture(self.h, _ptr(frames), code, B, T, _ptr(out)))
         return out
 
@@ -353,8 +364,14 @@ class Engine:
     def spot(self, gesture, content, g_offsets, c_offsets, targets, temp=0.07):
         self._bind_stream()
         g, c = self._f32(gesture), self._f32(content)
+        goh, coh, tgh = (np.asarray(a, np.int64) for a in (g_offsets, c_offsets, targets))
+        n = tgh.size
+        if goh.size != n + 1 or coh.size != n + 1:
+            raise ValueError("g_offsets / c_offsets need one entry more than targets")
+        T, W = np.diff(goh), np.diff(coh)
+        if n and (T.min() <= 0 or T.max() > 8192 or W.min() <= 0 or W.max() > 1024 or (tgh < 0).any() or (tgh >= W).any()):
+            raise ValueError("jg_spot limits: 1..8192 frames and 1..1024 words per clip, 0 <= target < words")
         go, co, tg = self._i32(g_offsets), self._i32(c_offsets), self._i32(targets)
-        n = tg.numel()
         pred = torch.empty(n, dtype=torch.int32, device=self.device)
         score = torch.empty(n, dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_spot(self.h, _ptr(g), _ptr(c), _ptr(go), _ptr(co), _ptr(tg), n, g.shape[-1], temp, _ptr(pred), _ptr(score)))

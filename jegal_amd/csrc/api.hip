@@ -30,6 +30,7 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     f16* wl_calib = nullptr;
     float* mu = nullptr;        // device [K]: column sums of the A operand seen during calibration
     long mu_rows = 0;
+    int model = 0;              // 1 GestSync, 2 JEGAL (which finalize owns this layer)
     std::vector<float> w32, b32;
 };
 struct LNp { float* w = nullptr; float* b = nullptr; };
@@ -71,13 +72,16 @@ struct jg_handle {
     int precision = JG_PREC_FP16_BC;
     bool calib = false;            // calibration pass in progress (bc layers use hi+lo and record input means)
     bool gs_calibrated = false, jg_calibrated = false;
-    std::vector<Lin*> bc_layers;
+    std::vector<Lin*> bc_layers;   // bias-corrected layers of both models (entries of a model are dropped on its re-finalize)
     int chunk = 8;
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     std::map<std::string, HostTensor> host;
-    std::vector<void*> wallocs;
+    std::vector<void*> wallocs_gs, wallocs_jg;   // device weights of the GestSync / JEGAL model (freed on re-finalize)
+    std::vector<void*>* wallocs = &wallocs_gs;   // list the model being finalized allocates into
+    int cur_model = 1;
+    EngineOpts opts;               // per-handle tuning switches + per-device resources (common.h)
     Arena ws;
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -108,6 +112,19 @@ namespace {
 #define HIPCHK(h, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 #define RET(expr) do { int _r = (expr); if (_r != JG_OK) return _r; } while (0)
 
+// Every entry point runs on the handle's device whatever the caller's current device is, and restores it afterwards:
+// workspace allocations, kernel launches and hipFuncSetAttribute all act on the CURRENT device.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ENTER(h) if (!(h)) return JG_ERR_ARG; DeviceGuard _dg((h)->device); if (!_dg.ok) JG_FAIL(h, JG_ERR_HIP, "hipSetDevice(%d) failed", (h)->device)
+
 // run a launcher under optional event timing
 template <class F>
 int timed(jg_handle* h, int stage, F&& f) {
@@ -130,7 +147,7 @@ template <class T>
 int walloc(jg_handle* h, size_t n, T** out) {
     void* p = nullptr;
     HIPCHK(h, hipMalloc(&p, n * sizeof(T) + 256));
-    h->wallocs.push_back(p);
+    h->wallocs->push_back(p);
     *out = reinterpret_cast<T*>(p);
     return JG_OK;
 }
@@ -181,6 +198,7 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
         if (split || bc) lo[i] = (f16)(w[i] - (float)a);
     }
     L->N = N; L->K = K;
+    L->model = h->cur_model;
     RET(upload(h, hi, &L->wh));
     L->wl = nullptr;
     if (split) RET(upload(h, lo, &L->wl));
@@ -280,7 +298,26 @@ int make_annotated_layer(jg_handle* h, const std::string& p, int D, int Dff, Enc
     return JG_OK;
 }
 
+// Re-finalizing a model (the drivers reload the state_dict on every command) frees that model's previous device
+// weights and drops its bias-corrected layers from the calibration list first.
+void drop_model(jg_handle* h, std::vector<void*>& allocs, int model) {
+    (void)hipStreamSynchronize(h->stream);
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+    std::vector<Lin*> keep;
+    for (Lin* L : h->bc_layers)
+        if (L->model != model) keep.push_back(L);
+    h->bc_layers.swap(keep);
+    h->cur_model = model;
+}
+
 int finalize_gestsync(jg_handle* h) {
+    h->gs_ready = false;
+    h->gs_calibrated = false;
+    drop_model(h, h->wallocs_gs, 1);
+    h->c1 = h->c2 = h->c3 = h->c4 = h->c5 = h->fc6 = h->ff0 = h->ff2 = Lin();
+    for (auto& L : h->gs_layers) L = EncLayer();
+    h->wallocs = &h->wallocs_gs;
     RET(make_conv(h, "net_vid.conv1", "net_vid.bn1", 64, 3, 5, 7, 7, 16, 0, &h->c1));
     // conv2..conv5: taps grouped by stride parity class (ConvGeom::taps); gs_conv_stack builds the same geometry
     RET(make_conv(h, "net_vid.conv2", "net_vid.bn2", 128, 64, 1, 5, 5, 64, 0, &h->c2, 2, 2, true));
@@ -326,6 +363,14 @@ int finalize_gestsync(jg_handle* h) {
 }
 
 int finalize_jegal(jg_handle* h) {
+    h->jg_ready = false;
+    h->jg_calibrated = false;
+    drop_model(h, h->wallocs_jg, 2);
+    h->ip0 = h->ip3 = h->op_rgb = h->al_g0 = h->al_g2 = h->fu0 = h->fu2 = h->al_c0 = h->al_c2 = h->op_text = h->op_audio = Lin();
+    h->a0 = h->a3 = h->a6 = h->a9 = h->a12 = h->a15 = Lin();
+    for (auto& L : h->rgb_layers) L = EncLayer();
+    for (auto& L : h->text_layers) L = EncLayer();
+    h->wallocs = &h->wallocs_jg;
     RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0));
     RET(make_ln(h, "proj_ip_rgb.1.weight", "proj_ip_rgb.1.bias", 512, &h->ip_ln));
     RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3));
@@ -389,12 +434,15 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     a.res16 = e.res16; a.res8 = e.res8; a.out8 = e.out8; a.a_tiled = e.a_tiled;
     const bool conv = g != nullptr;
     if (h->calib && L.bc && !conv) {
+        // column sums ACCUMULATE over every call of a calibration pass (chunks of a large calibration batch, the six
+        // layers' shared shapes are separate Lin objects): calibrate_impl zeroes mu / mu_rows once at its start
         Lin& Lm = const_cast<Lin&>(L);
-        HIPCHK(h, hipMemsetAsync(Lm.mu, 0, sizeof(float) * L.K, h->stream));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, Lm.mu, h->stream); }));
-        Lm.mu_rows = M;
+        float* part;
+        RET(wsalloc(h, col_sum_scratch_elems(L.K), &part));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, part, Lm.mu, h->stream); }));
+        Lm.mu_rows += M;
     }
-    return timed(h, stage, [&] { return launch_gemm(a, conv, h->stream); });
+    return timed(h, stage, [&] { return launch_gemm(a, conv, h->opts, h->stream); });
 }
 
 ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, bool reorder = false) {
@@ -444,7 +492,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         f16* edge;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, p1, edge, h->stream); }));
+                                                                   1.0f / 255.0f, p1, edge, h->opts, h->stream); }));
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -491,7 +539,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
         Epi e;
         e.out16 = qkv; e.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
         // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue (row-wide
         // 128x512 tiles, tiled fp16 + 8-bit token stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
         auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
@@ -595,7 +643,7 @@ int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& f
         RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
         Epi e; e.out16 = qkv;
         RET(gemm(h, JG_ST_GEMM, n16, D, M, L.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mask, B, S, H, dk, att, h->stream); }));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mask, B, S, H, dk, att, h->opts, h->stream); }));
         Epi r; r.res = x32; r.ldr = D; r.out32 = x32;
         RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
         RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
@@ -689,6 +737,10 @@ int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T) {
     float *feats = nullptr, *emb = nullptr;
     HIPCHK(h, hipMalloc(&feats, (size_t)B * T * 1024 * sizeof(float)));
     HIPCHK(h, hipMalloc(&emb, (size_t)B * T * 512 * sizeof(float)));
+    for (Lin* L : h->bc_layers) {
+        if (hipMemsetAsync(L->mu, 0, sizeof(float) * L->K, h->stream) != hipSuccess) { hipFree(feats); hipFree(emb); if (own) hipFree(own); JG_FAIL(h, JG_ERR_HIP, "hipMemsetAsync(mu) failed"); }
+        L->mu_rows = 0;
+    }
     h->calib = true;
     int rc = JG_OK;
     if (h->gs_ready) {
@@ -798,10 +850,16 @@ int jg_create(int device, jg_handle** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return JG_ERR_HIP;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     if (hipSetDevice(device) != hipSuccess) return JG_ERR_HIP;
     jg_handle* h = new jg_handle();
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return JG_ERR_HIP; }
+    int rc = JG_OK;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) rc = JG_ERR_HIP;
+    if (rc == JG_OK && engine_opts_init(h->opts, device) != hipSuccess) rc = JG_ERR_HIP;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc != JG_OK) { if (h->own_stream) (void)hipStreamDestroy(h->own_stream); delete h; return rc; }
     h->stream = h->own_stream;
     *out = h;
     return JG_OK;
@@ -809,17 +867,20 @@ int jg_create(int device, jg_handle** out) {
 
 int jg_destroy(jg_handle* h) {
     if (!h) return JG_OK;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
-    for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
-    for (void* p : h->wallocs) hipFree(p);
-    if (h->feats) hipFree(h->feats);
-    h->ws.release();
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    {
+        DeviceGuard dg(h->device);
+        hipDeviceSynchronize();
+        for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        for (void* p : h->wallocs_gs) hipFree(p);
+        for (void* p : h->wallocs_jg) hipFree(p);
+        if (h->feats) hipFree(h->feats);
+        h->ws.release();
+        engine_opts_release(h->opts);
+        if (h->own_stream) hipStreamDestroy(h->own_stream);
+    }
     delete h;
     return JG_OK;
 }
-
 const char* jg_last_error(jg_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 int jg_set_stream(jg_handle* h, void* s) {
@@ -831,7 +892,7 @@ int jg_set_stream(jg_handle* h, void* s) {
 int jg_set_precision(jg_handle* h, int mode) {
     if (!h) return JG_ERR_ARG;
     if (mode < JG_PREC_FP16 || mode > JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
-    if (h->gs_ready || h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
+    if ((h->gs_ready || h->jg_ready) && mode != h->precision) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
     h->precision = mode;
     return JG_OK;
 }
@@ -845,26 +906,25 @@ int jg_set_chunk(jg_handle* h, int c) {
 
 int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!h || !name) return JG_ERR_ARG;
+    EngineOpts& o = h->opts;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
-    if (!std::strcmp(name, "gemm_timeline")) { gemm_set_timeline(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "conv1_zero_skip")) { conv1_set_zero_skip(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "attn_mfma")) { attention_set_mfma(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_stagger")) { gemm_set_stagger(value); return JG_OK; }
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
-    if (!std::strcmp(name, "gemm_glds")) { gemm_set_glds(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_ring")) { gemm_set_ring(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_tall_tile")) { gemm_set_tall_tile(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_small_tile")) { gemm_set_small_tile(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_big_tile")) { gemm_set_big_tile(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_counted")) { gemm_set_counted(value); return JG_OK; }
-    if (!std::strcmp(name, "gemm_persistent")) { gemm_set_persistent(value != 0); return JG_OK; }
-    if (!std::strcmp(name, "gemm_ring_cfg")) { gemm_set_ring_cfg(value); return JG_OK; }
+    if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_tall_tile")) { o.gemm_tall_tile = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_small_tile")) { o.gemm_small_tile = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_big_tile")) { o.gemm_big_tile = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_counted")) { o.gemm_counted = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_persistent")) { o.gemm_persistent = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_stagger")) { o.gemm_stagger = value; return JG_OK; }
+    if (!std::strcmp(name, "gemm_timeline")) { DeviceGuard dg(h->device); engine_opts_set_timeline(o, value != 0); return JG_OK; }
     JG_FAIL(h, JG_ERR_ARG, "unknown option '%s'", name);
 }
 
 int jg_sync(jg_handle* h) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return JG_OK;
 }
@@ -889,29 +949,31 @@ int jg_load_tensor(jg_handle* h, const char* name, const void* data, const int64
 }
 
 int jg_finalize_weights(jg_handle* h, int which) {
-    if (!h) return JG_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    ENTER(h);
     if (which & 1) RET(finalize_gestsync(h));
     if (which & 2) RET(finalize_jegal(h));
+    // the fp32 host copies of the checkpoint (incl. the unused audio/LSTM tensors of gestsync.py:23-32) are no longer
+    // needed: packed device weights + the w32/b32 of the bias-corrected layers carry everything
+    h->host.clear();
     if (h->precision == JG_PREC_FP16_BC) RET(calibrate_impl(h, nullptr, JG_U8, 0, 0));
     return JG_OK;
 }
 
 int jg_calibrate_gesture(jg_handle* h, const void* frames, int dtype, int B, int T) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (h->precision != JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC");
     if (frames && (B <= 0 || T <= 0 || (dtype != JG_U8 && dtype != JG_F32))) JG_FAIL(h, JG_ERR_ARG, "bad calibration batch");
     return calibrate_impl(h, frames, dtype, B, T);
 }
 
 int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!frames || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return gestsync_clip_impl(h, frames, dtype, B, T, out);
 }
 
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
     if (!frames_u8 || !out_f16 || B <= 0 || T + 2 * pad < 5) JG_FAIL(h, JG_ERR_ARG, "bad arguments");
     h->ws.reset();
@@ -921,7 +983,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
         f16* edge;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         return timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, h->stream); });
+                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, h->opts, h->stream); });
     }
     f16 *o1, *S;
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
@@ -938,6 +1000,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
 // mode bit 0: hi+lo weights, bit 1: fp32 residual in/out (else fp16 out), bit 2: ReLU.  Returns ms per launch in *ms.
 int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms) {
     if (!h || !ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return JG_ERR_ARG;
+    ENTER(h);
     h->ws.reset();
     f16 *A, *Wh, *Wl, *o16;
     float *bias, *x32;
@@ -965,9 +1028,9 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, launch_gemm(a, false, h->stream));
+    HIPCHK(h, launch_gemm(a, false, h->opts, h->stream));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(a, false, h->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(a, false, h->opts, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
     float t = 0.f;
@@ -979,13 +1042,13 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
 }
 
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!x || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return gestsync_windows_impl(h, x, N, out, out_conv);
 }
 
 int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!feats || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
     return jegal_gestures_impl(h, feats, mask, B, T, align, out);
@@ -994,54 +1057,57 @@ int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B
 int jg_audio_len(int Tm) { return audio_len(Tm); }
 
 int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!mel || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
     return jegal_audio_impl(h, mel, B, Tm, out);
 }
 
 int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const int32_t* mask_y, uint8_t* dst) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!src || !mask_y || !dst || T <= 0 || H <= 0 || W <= 0) JG_FAIL(h, JG_ERR_ARG, "bad mask_resize arguments");
     return timed(h, JG_ST_MISC, [&] { return launch_mask_resize(src, T, H, W, mask_y, dst, h->stream); });
 }
 
 int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!wav || !mel_basis || !out || B <= 0 || n_samples < 160) JG_FAIL(h, JG_ERR_ARG, "bad logmel arguments");
     return timed(h, JG_ST_MISC, [&] { return launch_logmel(wav, B, n_samples, mel_basis, out, h->stream); });
 }
 
 int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!states || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
     return jegal_text_impl(h, states, mask, B, L, out);
 }
 
 int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!seq || !seg || !dst) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return timed(h, JG_ST_MISC, [&] { return launch_segment_mean(seq, D, seg, n, nullptr, dst, dst_ld, dst_col, h->stream); });
 }
 
 int jg_fuse_content(jg_handle* h, const float* fused, int rows, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!fused || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
     return fuse_content_impl(h, fused, rows, out);
 }
 
 int jg_l2norm(jg_handle* h, const float* in, float* out, int rows, int D) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!in || !out || D % 4) JG_FAIL(h, JG_ERR_ARG, "bad l2norm arguments");
     return timed(h, JG_ST_MISC, [&] { return launch_l2norm(in, out, rows, D, h->stream); });
 }
 
 int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_emb) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!frames || !out_emb) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    if (B <= 0 || T <= 0) JG_FAIL(h, JG_ERR_ARG, "B and T must be positive");
     if (T > 500) JG_FAIL(h, JG_ERR_ARG, "T must be <= 500");
+    if (dtype != JG_U8 && dtype != JG_F32) JG_FAIL(h, JG_ERR_ARG, "frames dtype must be JG_U8 or JG_F32");
+    if (!h->gs_ready || !h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync and JEGAL weights must both be finalized");
     // the (B,T,1024) GestSync features stay on the device in a buffer owned by the handle
     const size_t need_b = (size_t)B * T * 1024 * sizeof(float);
     if (need_b > h->feats_cap) {
@@ -1056,14 +1122,14 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
 }
 
 int jg_pool_mean(jg_handle* h, const float* x, const int32_t* off, int n, int D, float* out) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!x || !off || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return timed(h, JG_ST_MISC, [&] { return launch_ragged_mean(x, off, n, D, out, h->stream); });
 }
 
 int jg_sim_rank(jg_handle* h, const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
                 int32_t* rank, int32_t* ties) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!e1 || !e2 || !rank || !ties) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     if (D % 64 || row_offset < 0 || row_offset + n_local > n_total) JG_FAIL(h, JG_ERR_ARG, "bad sim_rank geometry");
     return timed(h, JG_ST_MISC, [&] { return launch_sim_rank(e1, e2, n_local, n_total, row_offset, D, rank, ties, h->stream); });
@@ -1071,13 +1137,13 @@ int jg_sim_rank(jg_handle* h, const float* e1, const float* e2, int n_local, int
 
 int jg_spot(jg_handle* h, const float* g, const float* c, const int32_t* goff, const int32_t* coff, const int32_t* target,
             int n, int D, float temp, int32_t* pred, float* score) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!g || !c || !goff || !coff || !target || !pred || !score) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return timed(h, JG_ST_MISC, [&] { return launch_spot(g, c, goff, coff, target, n, D, temp, pred, score, h->stream); });
 }
 
 int jg_asd(jg_handle* h, const float* q, const float* cand, const int32_t* coff, int n, int D, float temp, int32_t* pred) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (!q || !cand || !coff || !pred) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return timed(h, JG_ST_MISC, [&] { return launch_asd(q, cand, coff, n, D, temp, pred, h->stream); });
 }
@@ -1103,7 +1169,7 @@ static int prof_collect(jg_handle* h) {
 }
 
 int jg_profile_get(jg_handle* h, int stage, double* ms, int64_t* launches) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     if (stage < 0 || stage >= JG_ST_COUNT) JG_FAIL(h, JG_ERR_ARG, "bad stage");
     RET(prof_collect(h));
     if (ms) *ms = h->prof_ms[stage];
@@ -1112,7 +1178,7 @@ int jg_profile_get(jg_handle* h, int stage, double* ms, int64_t* launches) {
 }
 
 int jg_profile_reset(jg_handle* h) {
-    if (!h) return JG_ERR_ARG;
+    ENTER(h);
     RET(prof_collect(h));
     for (int i = 0; i < JG_ST_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
     return JG_OK;

@@ -1,12 +1,16 @@
 // Self-attention for short sequences (gfx950).  softmax(q k^T / sqrt(dk) [masked_fill(mask==0,-1e9)]) v
 //   gestsync.py:20-21 (nn.MultiheadAttention, S = 21, no mask), modules.py:61-75 (S = T <= 500 or
-//   L text tokens, key-padding mask).
-//
-// Attention is < 5 % of the path's FLOPs (S = 21: 0.9 of 133 MFLOP per window-layer), so this is a
-// VALU kernel organised for the LDS/VALU pipes rather than MFMA: one lane per query row, the head's
-// K/V rows staged in LDS as fp16 and read as wave-wide BROADCASTS (every lane of a sequence reads the
-// same 16 B), packed v_dot2_f32_f16 for q.k, online softmax over sub-blocks of 8 keys, fp32 state.
-// For S <= 32 one 64-lane wave carries floor(64/S) (sequence, head) pairs (3 windows x 21 rows).
+//   L text tokens, key-padding mask).  Attention is < 5 % of the path's FLOPs and HBM-bound (it reads the
+//   packed qkv rows once and writes the context rows once), so all three kernels are organised around the
+//   memory and LDS pipes; launch_attention() picks one:
+//     attn_mfma_s32_kernel   S <= 32, dk = 64, no mask (the GestSync windows, S = 21): one wave per (window, head),
+//                            S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16 with K/Q rows as operands straight
+//                            from global memory, softmax on the accumulators, P carried as fp16 hi+lo.
+//     attn_mfma_kernel<NB>   S <= 160, dk = 64, optional key mask (JEGAL gesture encoder at the dataset's clip lengths):
+//                            one workgroup per (clip, head), K and V^T staged in LDS once, one wave per 32 queries.
+//     attn_kernel<DK>        everything else (160 < S <= 500, the text encoder's dk = 96): VALU kernel, one lane per
+//                            query row, K/V rows in LDS read as wave-wide broadcasts, v_dot2_f32_f16, online softmax
+//                            over blocks of 8 keys, fp32 state.  For S <= 32 one wave carries floor(64/S) (sequence, head) pairs.
 #include "common.h"
 
 template <int DK>
@@ -419,17 +423,14 @@ static hipError_t launch_attn_mfma(const f16* qkv, const float* keymask, long np
     return hipGetLastError();
 }
 
-static bool g_attn_mfma = true;
-void attention_set_mfma(bool on) { g_attn_mfma = on; }
-
-hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, hipStream_t s) {
+hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, const EngineOpts& o, hipStream_t s) {
     if (B <= 0 || S <= 0) return hipSuccess;
     const long npairs = (long)B * H;
-    if (g_attn_mfma && S <= 32 && dk == 64 && !keymask && npairs < (1L << 31)) {
+    if (o.attn_mfma && S <= 32 && dk == 64 && !keymask && npairs < (1L << 31)) {
         hipLaunchKernelGGL(attn_mfma_s32_kernel, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out);
         return hipGetLastError();
     }
-    if (g_attn_mfma && S <= 160 && dk == 64 && npairs < (1L << 31)) {      // S <= 32 with a key mask: one query block
+    if (o.attn_mfma && S <= 160 && dk == 64 && npairs < (1L << 31)) {      // S <= 32 with a key mask: one query block
         switch ((S + 31) / 32) {
             case 1: return launch_attn_mfma<1>(qkv, keymask, npairs, S, H, out, s);
             case 2: return launch_attn_mfma<2>(qkv, keymask, npairs, S, H, out, s);

@@ -99,34 +99,42 @@ __device__ __forceinline__ int res_enc(float y, f16 h) {
 enum { LN_STD = 0, LN_ANNOTATED = 1 };
 
 
+// ---- per-handle engine state shared with the launchers ---------------------------------------------------------
+// Tuning / A-B switches and the per-device resources a launch needs.  One instance per jg_handle (api.hip), passed to
+// the launchers: two handles -- on one device or on two -- never see each other's settings.
+struct EngineOpts {
+    int device = 0;
+    int num_cu = 256;
+    const f16* zeros = nullptr;          // 256-byte zero page on `device` (LDS-DMA source for padding taps / K tails)
+    bool gemm_glds = true;               // LDS-DMA GEMM kernels (false: register-staged gemm_kernel everywhere)
+    bool gemm_persistent = true;
+    bool gemm_big_tile = true, gemm_small_tile = true, gemm_tall_tile = true;
+    int gemm_counted = 1;                // counted s_waitcnt between a tile's epilogue stores and the next tile's first DMA
+    int gemm_stagger = 0;                // 10-ns ticks per phase (0: default policy, -1: off)
+    unsigned long long* gemm_tl = nullptr;   // debug timeline buffer (option gemm_timeline)
+    bool attn_mfma = true;
+    bool conv1_zero_skip = true;
+};
+hipError_t engine_opts_init(EngineOpts& o, int device);      // queries the CU count, allocates the zero page (current device = `device`)
+void engine_opts_release(EngineOpts& o);
+void engine_opts_set_timeline(EngineOpts& o, bool on);
+
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
-hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStream_t s);
 bool gemm_ln_fusable(const GemmArgs& a);
-void gemm_set_glds(bool on);
-void gemm_set_ring(bool on);
-void gemm_set_ring_cfg(int c);
-void gemm_set_persistent(bool on);
-void gemm_set_counted(int on);
-void gemm_set_stagger(int ticks);
-void attention_set_mfma(bool on);
-void conv1_set_zero_skip(bool on);
 hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s);
-void gemm_set_timeline(bool on);
-void gemm_set_big_tile(bool on);
-void gemm_set_small_tile(bool on);
-void gemm_set_tall_tile(bool on);
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, hipStream_t s);
+                               f16* out_pooled, f16* edge, const EngineOpts& o, hipStream_t s);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s);
 hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,
                             int relu, float* out32, f16* out16, hipStream_t s);
-hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, hipStream_t s);
+hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, const EngineOpts& o, hipStream_t s);
 hipError_t launch_group_mean(const f16* in, int groups, int L, int D, f16* out, hipStream_t s);
 hipError_t launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s);
 hipError_t launch_transpose_tokens(const float* in, int N, int L, int D, float* out, hipStream_t s);
@@ -136,7 +144,8 @@ hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int 
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
 hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s);
-hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipStream_t s);
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s);
+size_t col_sum_scratch_elems(int K);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
                            int32_t* rank, int32_t* ties, hipStream_t s);

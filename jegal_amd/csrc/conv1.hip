@@ -442,27 +442,16 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
     *reinterpret_cast<f16x8*>(o) = max8(*reinterpret_cast<const f16x8*>(o), e);
 }
 
-static bool g_zero_skip = true;
-void conv1_set_zero_skip(bool on) { g_zero_skip = on; }
-
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, hipStream_t s) {
-    static int num_cu = 0;
-    static bool attr_set = false;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        e = hipGetDeviceProperties(&prop, dev);
-        if (e != hipSuccess) return e;
-        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    if (!attr_set) {
+                               f16* out_pooled, f16* edge, const EngineOpts& o, hipStream_t s) {
+    static bool attr_set[64] = {};
+    if (o.device < 0 || o.device >= 64) return hipErrorInvalidDevice;
+    const int num_cu = o.num_cu;
+    if (!attr_set[o.device]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[o.device] = true;
     }
     Conv1Args a;
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
@@ -472,7 +461,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.invP = 1.0f / (float)a.P;
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;
-    a.zskip = g_zero_skip ? 1 : 0;
+    a.zskip = o.conv1_zero_skip ? 1 : 0;
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
     if (want_tl && !tl && hipHostMalloc(&tl, 4096 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) tl = nullptr;

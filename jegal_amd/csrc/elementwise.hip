@@ -372,7 +372,10 @@ hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int
 // Column sums of a row-major fp16 matrix (calibration pass of the bias-corrected precision mode):
 // out[k] += sum_m A[m][k].  8 columns per thread, rows strided over blockIdx.y, one float atomic per
 // (thread, column) at the end.  `out` is zeroed by the caller.
-__global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K, float* __restrict__ out) {
+// Deterministic (no atomics): 64 row-strided partial sums per column go to `part` [gy][K], then one thread per column
+// adds them to out[] in a fixed order.  out ACCUMULATES across calls (stream order), so a calibration batch may arrive
+// in chunks and two handles calibrated on the same data end up with bit-identical bias corrections.
+__global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K, float* __restrict__ part) {
     const int c8 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c8 * 8 >= K) return;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -382,14 +385,24 @@ __global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K
         for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + c8 * 8 + e, acc[e]);
+    for (int e = 0; e < 8; ++e) part[(long)blockIdx.y * K + c8 * 8 + e] = acc[e];
+}
+__global__ void col_sum_finish_kernel(const float* __restrict__ part, int gy, int K, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int y = 0; y < gy; ++y) s += part[(long)y * K + k];
+    out[k] += s;
 }
 
-hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* out, hipStream_t s) {
+size_t col_sum_scratch_elems(int K) { return (size_t)64 * K; }
+
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s) {
     if (M <= 0 || K <= 0) return hipSuccess;
     const int cols = K / 8;
     const int gy = M < 64 ? M : 64;
-    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, out);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, scratch);
+    hipLaunchKernelGGL(col_sum_finish_kernel, dim3((K + 255) / 256), dim3(256), 0, s, scratch, gy, K, out);
     return hipGetLastError();
 }
 

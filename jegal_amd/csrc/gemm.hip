@@ -244,12 +244,16 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     // of ONE tap, so (kh, kw, c0) are wave-uniform and simply advance with the k-tiles (stage() is always called for
     // kt = 0, 1, 2, ... of a tile); per lane only the pointer to its (pixel, chunk) at tap (0,0) -- possibly outside
     // the image for padded layers, dereferenced only when the tap lands inside -- and the pixel coordinates remain.
+    // Register budget (the 128x512 and 512x128 instances sit at the 256-VGPR limit): the pixel coordinates of a conv row
+    // share one register (ih << 16 | iw & 0xffff), and the WI weight-row pointers are two base pointers (even / odd
+    // 8-row piece: the swizzled chunk depends on the piece's parity only) plus a wave-uniform multiple of 16 rows.
     const f16* xsrc[XI];
-    int xih[XI], xiw[XI];
+    int xpix[XI];
     int tidx = 0, tc0 = 0;
-    const f16* whsrc[WI];
-    const f16* wlsrc[WI];
-    int wchunk[WI];
+    static_assert(WI % 2 == 0, "weight pieces come in even/odd pairs");
+    const f16* whb[2];
+    const f16* wlb[2];
+    int wchunk[2];
     int n0 = 0, m0 = 0;
     auto setup = [&](int bid) {
         n0 = (bid % n_tiles) * BN;
@@ -264,24 +268,24 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const int per = a.g.OH * a.g.OW;
                 const int img = m / per, rem = m - img * per;
                 const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
-                xih[i] = oh * a.g.SH - a.g.PH;
-                xiw[i] = ow * a.g.SW - a.g.PW;
-                xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)xih[i] * a.g.W + xiw[i]) * a.g.C + c * 8;
+                const int ih = oh * a.g.SH - a.g.PH, iw = ow * a.g.SW - a.g.PW;
+                xpix[i] = (ih << 16) | (iw & 0xffff);
+                xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
             } else {
-                xih[i] = xiw[i] = 0;
+                xpix[i] = 0;
                 xsrc[i] = a.a_tiled ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) * 1024 + (m & 15) * 16 + (c >> 1) * 256 + (c & 1) * 8
                                     : a.A + (long)m * a.lda + c * 8;
             }
         }
+        // N % BN == 0 (launch_gemm sends anything else to gemm_kernel): no row clamp, piece i = base[i & 1] + (i >> 1) * 16 rows
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = (wave * WI + i) * 8 + lrow;
+        for (int par = 0; par < 2; ++par) {
+            const int row = (wave * WI + par) * 8 + lrow;
             const int c = pc ^ ((row >> 1) & 7);
-            int n = n0 + row;
-            n = n < a.N ? n : a.N - 1;
-            whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
-            wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
-            wchunk[i] = c;
+            const long off = (long)(n0 + row) * a.ldw + c * 8;
+            whb[par] = a.Wh + off;
+            wlb[par] = W2 ? a.Wl + off : nullptr;
+            wchunk[par] = c;
         }
     };
     // One k-tile = NPIECE LDS-DMA instructions per wave (XI activation pieces, then WI weight pieces, then the lo
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             const int i = p;
             const f16* src;
             if (CONV) {
-                const int ih = xih[i] + stkh, iw = xiw[i] + stkw;
+                const int ih = (xpix[i] >> 16) + stkh, iw = (int)(short)(xpix[i] & 0xffff) + stkw;
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
             } else {
@@ -327,12 +331,14 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             else __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
         } else if (p < XI + WI) {
             const int i = p - XI;
-            const bool kok = !CONV || (sk0 + wchunk[i] * 8 < a.K);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + sk0 : zeros), (lds_ptr_t)(base + XB + (wave * WI + i) * 1024), 16, 0, 0);
+            const bool kok = !CONV || (sk0 + wchunk[i & 1] * 8 < a.K);
+            const f16* wsrc = whb[i & 1] + (long)(i >> 1) * 16 * a.ldw + sk0;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wsrc : zeros), (lds_ptr_t)(base + XB + (wave * WI + i) * 1024), 16, 0, 0);
         } else if (W2 && p < NPIECE) {
             const int i = p - XI - WI;
-            const bool kok = !CONV || (sk0 + wchunk[i] * 8 < a.K);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + sk0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * WI + i) * 1024), 16, 0, 0);
+            const bool kok = !CONV || (sk0 + wchunk[i & 1] * 8 < a.K);
+            const f16* wsrc = wlb[i & 1] + (long)(i >> 1) * 16 * a.ldw + sk0;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wsrc : zeros), (lds_ptr_t)(base + XB + WB + (wave * WI + i) * 1024), 16, 0, 0);
         }
     };
     auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
@@ -744,25 +750,22 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     }
 }
 
-static bool g_persistent = true;
-static int g_counted = 1;
-void gemm_set_persistent(bool on) { g_persistent = on; }
-void gemm_set_counted(int on) { g_counted = on; }
-static int g_stagger = 0;       // 10-ns ticks per phase (4 phases)
-void gemm_set_stagger(int ticks) { g_stagger = ticks; }
-static unsigned long long* g_tl = nullptr;
-void gemm_set_timeline(bool on) {
-    if (on && !g_tl) {
-        if (hipHostMalloc(&g_tl, 1024 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) g_tl = nullptr;
-    } else if (!on && g_tl) {
-        (void)hipHostFree(g_tl);
-        g_tl = nullptr;
+// ---- host side.  Every tuning switch and per-device resource lives in the caller's EngineOpts (one per jg_handle):
+// nothing here is process-global except the "dynamic LDS attribute set" flags, which are per (kernel, device).
+constexpr int MAX_DEV = 64;
+
+void engine_opts_set_timeline(EngineOpts& o, bool on) {
+    if (on && !o.gemm_tl) {
+        if (hipHostMalloc(&o.gemm_tl, 1024 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) o.gemm_tl = nullptr;
+    } else if (!on && o.gemm_tl) {
+        (void)hipHostFree(o.gemm_tl);
+        o.gemm_tl = nullptr;
     }
 }
-static void dump_timeline(hipStream_t s, const char* what) {
+static void dump_timeline(const EngineOpts& o, hipStream_t s, const char* what) {
     (void)hipStreamSynchronize(s);
     for (int b = 0; b < 2; ++b) {
-        const unsigned long long* t = g_tl + b * 512;
+        const unsigned long long* t = o.gemm_tl + b * 512;
         std::fprintf(stderr, "[gemm timeline %s wg %s] (100 MHz ticks -> us)\n", what, b ? "last" : "0");
         for (int i = 0; i + 3 < 512 && t[i + 3]; i += 4) {
             std::fprintf(stderr, "  tile %2d: kloop %6.2f  setup+dma-issue %5.2f  epilogue %5.2f  wait-next %5.2f\n", i / 4, (t[i + 1] - t[i]) * 0.01,
@@ -771,79 +774,80 @@ static void dump_timeline(hipStream_t s, const char* what) {
     }
 }
 
-static const f16* zero_page() {
-    static f16* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        (void)hipMemset(z, 0, 256);
+hipError_t engine_opts_init(EngineOpts& o, int device) {
+    o.device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    o.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    f16* z = nullptr;
+    e = hipMalloc(&z, 256);                  // zero page on THIS device: LDS-DMA cannot predicate, but it can read zeros
+    if (e != hipSuccess) return e;
+    e = hipMemset(z, 0, 256);
+    if (e != hipSuccess) return e;
+    o.zeros = z;
+    return hipSuccess;
+}
+
+void engine_opts_release(EngineOpts& o) {
+    if (o.zeros) (void)hipFree(const_cast<f16*>(o.zeros));
+    o.zeros = nullptr;
+    engine_opts_set_timeline(o, false);
+}
+
+template <class K>
+static hipError_t ensure_lds_attr(K kernel, size_t lds, int device, bool* flags) {
+    if (device < 0 || device >= MAX_DEV) return hipErrorInvalidDevice;
+    if (!flags[device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        flags[device] = true;
     }
-    return z;
+    return hipSuccess;
 }
 
 template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false>
-static hipError_t launch_glds_cfg(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStream_t s) {
+    static bool attr_set[MAX_DEV] = {};
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr size_t lds = 2 * (size_t)(BM * 128 + BN * 128 * (W2 ? 2 : 1));
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const f16* z = zero_page();
-    if (!z) return hipErrorOutOfMemory;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    hipError_t e = ensure_lds_attr(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>, lds, o.device, attr_set);
+    if (e != hipSuccess) return e;
+    if (!o.zeros) return hipErrorInvalidValue;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const int tiles = mt * nt;
-    const int grid = g_persistent ? (tiles < num_cu ? tiles : num_cu) : tiles;
-    if (g_tl) {
+    const int grid = o.gemm_persistent ? (tiles < o.num_cu ? tiles : o.num_cu) : tiles;
+    if (o.gemm_tl) {
         (void)hipStreamSynchronize(s);
-        std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
+        std::memset(o.gemm_tl, 0, 1024 * sizeof(unsigned long long));
     }
     // De-phasing the workgroups (4 phases, 2 us apart; the last phase falls on the workgroups that run one tile fewer):
     // once the outputs were nontemporal the epilogues became HBM-write-burst bound (every CU stores its 128 KB at the
     // same moment) and spreading them pays: qkv 157 -> 146 us.  Only for long plain GEMMs (>= 4 rounds); the LN-fused
     // and conv kernels and short launches measured neutral or slower.  Option gemm_stagger: ticks of 10 ns, -1 = off.
-    const int stagger = g_stagger < 0 ? 0 : g_stagger > 0 ? g_stagger : (!CONV && tiles >= 4 * num_cu ? 200 : 0);
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, z, g_counted | (stagger << 8), g_tl);
-    if (g_tl) dump_timeline(s, CONV ? "conv" : "linear");
+    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger : (!CONV && tiles >= 4 * o.num_cu ? 200 : 0);
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
+                       o.gemm_counted | (stagger << 8), o.gemm_tl);
+    if (o.gemm_tl) dump_timeline(o, s, CONV ? "conv" : "linear");
     return hipGetLastError();
 }
 
 template <bool CONV>
-static hipError_t launch_glds_ln(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+static hipError_t launch_glds_ln(const GemmArgs& a, const EngineOpts& o, hipStream_t s) {
+    static bool attr_set[MAX_DEV] = {};
     constexpr size_t lds = 2 * (size_t)(128 * 128 + 512 * 128);          // 160 KiB: the whole LDS
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<false, CONV, 8, 1, 8, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const f16* z = zero_page();
-    if (!z) return hipErrorOutOfMemory;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    hipError_t e = ensure_lds_attr(gemm_glds_kernel<false, CONV, 8, 1, 8, true>, lds, o.device, attr_set);
+    if (e != hipSuccess) return e;
+    if (!o.zeros) return hipErrorInvalidValue;
     const int tiles = (a.M + 127) / 128;
-    const int grid = tiles < num_cu ? tiles : num_cu;
-    if (g_tl) {
+    const int grid = tiles < o.num_cu ? tiles : o.num_cu;
+    if (o.gemm_tl) {
         (void)hipStreamSynchronize(s);
-        std::memset(g_tl, 0, 1024 * sizeof(unsigned long long));
+        std::memset(o.gemm_tl, 0, 1024 * sizeof(unsigned long long));
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, z, g_counted | ((g_stagger > 0 ? g_stagger : 0) << 8), g_tl);
-    if (g_tl) dump_timeline(s, "linear+LN");
+    hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, o.zeros,
+                       o.gemm_counted | ((o.gemm_stagger > 0 ? o.gemm_stagger : 0) << 8), o.gemm_tl);
+    if (o.gemm_tl) dump_timeline(o, s, "linear+LN");
     return hipGetLastError();
 }
 
@@ -852,267 +856,25 @@ bool gemm_ln_fusable(const GemmArgs& a) {
            !a.res && !a.out32 && a.res16 && a.res8 && a.out16 && a.out8 && !a.a_tiled;
 }
 
-static bool g_big_tile = true;
-static bool g_small_tile = true;
-static bool g_tall_tile = true;
-void gemm_set_big_tile(bool on) { g_big_tile = on; }
-void gemm_set_small_tile(bool on) { g_small_tile = on; }
-void gemm_set_tall_tile(bool on) { g_tall_tile = on; }
-
 template <bool W2, bool CONV>
-static hipError_t launch_glds(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_t s) {
     // small problems (the JEGAL branch: M = B*T = 4800 tokens) would leave most CUs idle with 256-row tiles:
     // 128x128 tiles (32x64 wave tiles) give 4x the workgroups
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
-    if (g_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, s);
+    if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, o, s);
     if constexpr (!W2) {
-        if (g_big_tile && a.N >= 256 && a.N % 256 == 0) {
-            if (!CONV && a.K <= 1024) return launch_glds_cfg<false, CONV, 8, 2, 4, !CONV>(a, s);       // short k loops: spread DMA issue
-            return launch_glds_cfg<false, CONV, 8, 2, 4>(a, s);
+        if (o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0) {
+            if (!CONV && a.K <= 1024) return launch_glds_cfg<false, CONV, 8, 2, 4, !CONV>(a, o, s);       // short k loops: spread DMA issue
+            return launch_glds_cfg<false, CONV, 8, 2, 4>(a, o, s);
         }
         // N = 128 (conv2): 512x128 block tile, the whole 160 KiB of LDS -- the activation side dominates the
         // L2->LDS traffic there, a taller tile halves the weight re-reads per activation byte
-        if (g_tall_tile && a.N == 128 && a.M >= 512 * 256) return launch_glds_cfg<false, CONV, 8, 4, 2>(a, s);
-    }
-    return launch_glds_cfg<W2, CONV, 4, 4, 2>(a, s);
-}
-
-template <bool W2, bool CONV, int WM, int WN, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmArgs a, int n_tiles, int total_blocks, const f16* zeros) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
-    constexpr int XI = (BM / 16) / NW, WI = (BN / 16) / NW;   // LDS-DMA instructions per wave per half-stage
-    constexpr int DIST = NS - 1;                              // half-stages issued ahead
-    constexpr int XB = BM * 64, WB = BN * 64;
-    constexpr int SLOTB = XB + WB * (W2 ? 2 : 1);
-    constexpr int PER = XI + WI * (W2 ? 2 : 1);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave % WM, wn = wave / WM;
-    int bid = blockIdx.x;
-    {
-        const int q = total_blocks / 8, rr = total_blocks % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    }
-    const int n0 = (bid % n_tiles) * BN;
-    const int m0 = (bid / n_tiles) * BM;
-
-    // wave-instruction i covers tile rows (wave*R + i)*16 .. +16; lane -> (row = l>>2, phys chunk = l&3)
-    const int lrow = lane >> 2, pc = lane & 3;
-    const f16* xsrc[XI];
-    int xih[XI], xiw[XI], xchunk[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int row = (wave * XI + i) * 16 + lrow;
-        const int c = pc ^ (((row >> 3) & 1) * 2);
-        int m = m0 + row;
-        m = m < a.M ? m : a.M - 1;
-        xchunk[i] = c;
-        if (CONV) {
-            const int per = a.g.OH * a.g.OW;
-            const int img = m / per, rem = m - img * per;
-            const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
-            xih[i] = oh * a.g.SH - a.g.PH;
-            xiw[i] = ow * a.g.SW - a.g.PW;
-            xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C;
-        } else {
-            xih[i] = xiw[i] = 0;
-            xsrc[i] = a.A + (long)m * a.lda + c * 8;
+        if constexpr (CONV) {
+            if (o.gemm_tall_tile && a.N == 128 && a.M >= 512 * 256) return launch_glds_cfg<false, true, 8, 4, 2>(a, o, s);
         }
     }
-    const f16* whsrc[WI];
-    const f16* wlsrc[WI];
-    int wchunk[WI];
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int row = (wave * WI + i) * 16 + lrow;
-        const int c = pc ^ (((row >> 3) & 1) * 2);
-        int n = n0 + row;
-        n = n < a.N ? n : a.N - 1;
-        whsrc[i] = a.Wh + (long)n * a.ldw + c * 8;
-        wlsrc[i] = W2 ? a.Wl + (long)n * a.ldw + c * 8 : nullptr;
-        wchunk[i] = c;
-    }
-
-    auto stage = [&](int hs) {
-        char* base = smem + (hs % NS) * SLOTB;
-        const int k0 = hs * 32;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const f16* src;
-            if (CONV) {
-                const int k = k0 + xchunk[i] * 8;
-                const int ci = k & (a.g.C - 1);
-                const int kp = k >> a.g.cshift;
-                int kh, kw;
-                    tap_decode(a.g, kp, kh, kw);
-                const int ih = xih[i] + kh, iw = xiw[i] + kw;
-                const bool ok = k < a.K && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
-                src = ok ? xsrc[i] + ((long)ih * a.g.W + iw) * a.g.C + ci : zeros;
-            } else {
-                src = xsrc[i] + k0;
-            }
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + (wave * XI + i) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const bool kok = !CONV || (k0 + wchunk[i] * 8 < a.K);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? whsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + (wave * WI + i) * 1024), 16, 0, 0);
-            if (W2)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(kok ? wlsrc[i] + k0 : zeros), (lds_ptr_t)(base + XB + WB + (wave * WI + i) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nh = (a.K + 31) / 32;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int choff = (fq ^ (((frow >> 3) & 1) * 2)) << 4;
-
-#pragma unroll
-    for (int d = 0; d < DIST; ++d)
-        if (d < nh) stage(d);
-    for (int hs = 0; hs < nh; ++hs) {
-        // retire half-stage hs (this wave's own DMA), leave the younger ones in flight
-        const int later = nh - 1 - hs;
-        if (DIST >= 3 && later >= 2) wait_vmcnt<2 * PER>();
-        else if (DIST >= 2 && later >= 1) wait_vmcnt<PER>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();      // everyone's part of hs has landed; slot (hs+DIST)%NS == (hs-1)%NS is free
-        if (hs + DIST < nh) stage(hs + DIST);
-        const char* sX = smem + (hs % NS) * SLOTB;
-        const char* sWh = sX + XB;
-        const char* sWl = sWh + WB;
-        f16x8 wf[4], wl[4], xf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wn * 64 + i * 16 + frow;
-            wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 64 + choff);
-            if (W2) wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 64 + choff);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wm * 64 + j * 16 + frow;
-            xf[j] = *reinterpret_cast<const f16x8*>(sX + row * 64 + choff);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
-            }
-    }
-
-    const bool interior = m0 + BM <= a.M && n0 + BN <= a.N;
-    if (interior) {
-        const int nb = n0 + wn * 64 + fq * 4;
-        const int mb = m0 + wm * 64 + frow;
-        f32x4 sc[4], bi[4], rs[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
-            bi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rs[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (a.scale) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
-        }
-        if (a.bias) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
-        }
-        if (a.res) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = mb + j * 16;
-                const int rr = a.res_mod ? (m % a.res_mod) : m;
-                const float* rp = a.res + (long)rr * a.ldr + nb;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rs[i][j] = *reinterpret_cast<const f32x4*>(rp + i * 16);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long mo = (long)(mb + j * 16) * a.ldc + nb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v = acc[i][j] * sc[i] + bi[i] + rs[i][j];
-                if (a.relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = v;
-                if (a.out16) {
-                    f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                    *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = h;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + fq * 4;
-        if (n >= a.N) continue;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-        if (a.bias) bi = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + frow;
-            if (m >= a.M) continue;
-            f32x4 v = acc[i][j] * sc + bi;
-            if (a.res) {
-                const int rr = a.res_mod ? (m % a.res_mod) : m;
-                v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
-            }
-            if (a.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
-            if (a.out16) {
-                f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
-            }
-        }
-    }
-}
-
-template <bool W2, bool CONV, int WM, int WN, int NS>
-static hipError_t launch_ring_cfg(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr size_t lds = NS * (size_t)(BM * 64 + BN * 64 * (W2 ? 2 : 1));
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<W2, CONV, WM, WN, NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const f16* z = zero_page();
-    if (!z) return hipErrorOutOfMemory;
-    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_ring_kernel<W2, CONV, WM, WN, NS>), dim3((unsigned)(mt * nt)), dim3(64 * WM * WN), lds, s, a, nt, mt * nt, z);
-    return hipGetLastError();
-}
-
-static int g_ring_cfg = 1;     // 0: 256x128 tile, 8 waves, 4-slot ring (1 WG/CU); 1: 128x128, 4 waves, 2 slots (3 WG/CU); 2: 128x128, 3 slots
-void gemm_set_ring_cfg(int c) { g_ring_cfg = c; }
-
-template <bool W2, bool CONV>
-static hipError_t launch_ring(const GemmArgs& a, hipStream_t s) {
-    if (g_ring_cfg == 1) return launch_ring_cfg<W2, CONV, 2, 2, 2>(a, s);
-    if (g_ring_cfg == 2) return launch_ring_cfg<W2, CONV, 2, 2, 3>(a, s);
-    if (g_ring_cfg == 3) return launch_ring_cfg<W2, CONV, 4, 2, 2>(a, s);     // 256x128, 64 KB (W2): 2 WG/CU
-    return launch_ring_cfg<W2, CONV, 4, 2, 4>(a, s);
+    return launch_glds_cfg<W2, CONV, 4, 4, 2>(a, o, s);
 }
 
 template <int WM, int WN, bool CONV, bool W2>
@@ -1124,32 +886,22 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-static bool g_use_glds = true;
-static bool g_use_ring = false;   // measured r1: the ring variants are 5-15 % slower than the 2-stage kernel
-void gemm_set_glds(bool on) { g_use_glds = on; }
-void gemm_set_ring(bool on) { g_use_ring = on; }
-
-hipError_t launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.ln_w) {
         if (conv || !gemm_ln_fusable(a)) return hipErrorInvalidValue;
-        return launch_glds_ln<false>(a, s);
+        return launch_glds_ln<false>(a, o, s);
     }
     const bool w2 = a.Wl != nullptr;
     const bool narrow = a.N <= 64;
-    if (a.a_tiled && (conv || narrow || !g_use_glds || g_use_ring || a.K != 512 || a.M < 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
+    if (a.a_tiled && (conv || narrow || !o.gemm_glds || a.K != 512 || a.M < 128 || a.N % 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
     if (conv) {
         if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
-        if (g_use_glds && a.M >= 256 && a.g.C % 64 == 0) {
-            if (g_use_ring) return w2 ? launch_ring<true, true>(a, s) : launch_ring<false, true>(a, s);
-            return w2 ? launch_glds<true, true>(a, s) : launch_glds<false, true>(a, s);
-        }
+        if (o.gemm_glds && a.M >= 256 && a.g.C % 64 == 0 && a.N % 128 == 0) return w2 ? launch_glds<true, true>(a, o, s) : launch_glds<false, true>(a, o, s);
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);
-    if (g_use_glds && a.K % 64 == 0 && a.M >= 128 && a.lda % 8 == 0 && a.ldw % 8 == 0) {
-        if (g_use_ring) return w2 ? launch_ring<true, false>(a, s) : launch_ring<false, false>(a, s);
-        return w2 ? launch_glds<true, false>(a, s) : launch_glds<false, false>(a, s);
-    }
+    if (o.gemm_glds && a.K % 64 == 0 && a.M >= 128 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.N % 128 == 0)
+        return w2 ? launch_glds<true, false>(a, o, s) : launch_glds<false, false>(a, o, s);
     return w2 ? launch_variant<2, 2, false, true>(a, s) : launch_variant<2, 2, false, false>(a, s);
 }

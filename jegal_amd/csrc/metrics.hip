@@ -107,7 +107,7 @@ hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_
 // ---------------------------------------------------------------------------------------------
 // Word spotting (evaluate_spotting.py:39-82): per clip A = softmax((G C^T)/temp, dim=1) over words
 // with re-normalised rows; pred = first argmax_t A[t][w*], score = A[pred][w*].
-// One block per clip, one wave per frame row; lane w keeps logit w (W <= 64).
+// One block per clip, one wave per frame row; the W logits of a row go through a per-wave LDS line.
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -119,17 +119,26 @@ __device__ __forceinline__ float wmax(float v) {
     return v;
 }
 
+// Limits: W <= SPOT_MAX_W words and T <= SPOT_MAX_T frames per clip (LDS arrays), 0 <= target < W.  The offsets are device
+// arrays, so the host cannot check them without a sync: a clip outside the limits gets pred = -1, score = NaN.
+constexpr int SPOT_MAX_W = 1024, SPOT_MAX_T = 8192;
+
 __global__ __launch_bounds__(256) void spot_kernel(const float* __restrict__ g, const float* __restrict__ c,
                                                    const int32_t* __restrict__ goff, const int32_t* __restrict__ coff,
                                                    const int32_t* __restrict__ target, int D, float temp,
                                                    int32_t* __restrict__ pred, float* __restrict__ score) {
-    __shared__ float sCn[64];        // 1/max(||c_w||, eps)
-    __shared__ float sA[2048];       // A[t][w*]
+    __shared__ float sCn[SPOT_MAX_W];        // 1/max(||c_w||, eps)
+    __shared__ float sL[4][SPOT_MAX_W];      // per wave: the logits of the frame it is working on
+    __shared__ float sA[SPOT_MAX_T];         // A[t][w*]
     const int clip = blockIdx.x;
     const int t0 = goff[clip], T = goff[clip + 1] - t0;
     const int w0 = coff[clip], W = coff[clip + 1] - w0;
     const int wt = target[clip];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (T <= 0 || T > SPOT_MAX_T || W <= 0 || W > SPOT_MAX_W || wt < 0 || wt >= W) {      // block-uniform
+        if (threadIdx.x == 0) { pred[clip] = -1; score[clip] = __builtin_nanf(""); }
+        return;
+    }
     for (int w = wave; w < W; w += 4) {
         float sq = 0.f;
         for (int d = lane; d < D; d += 64) { const float v = c[(long)(w0 + w) * D + d]; sq += v * v; }
@@ -137,24 +146,31 @@ __global__ __launch_bounds__(256) void spot_kernel(const float* __restrict__ g, 
         if (lane == 0) sCn[w] = 1.f / fmaxf(sqrtf(sq), 1e-12f);
     }
     __syncthreads();
+    float* L = sL[wave];
     for (int t = wave; t < T; t += 4) {
         const float* gr = g + (long)(t0 + t) * D;
         float sq = 0.f;
         for (int d = lane; d < D; d += 64) { const float v = gr[d]; sq += v * v; }
         const float gn = 1.f / fmaxf(sqrtf(wsum(sq)), 1e-12f);
-        float mylogit = -INFINITY;
         for (int w = 0; w < W; ++w) {
             const float* cr = c + (long)(w0 + w) * D;
             float dot = 0.f;
             for (int d = lane; d < D; d += 64) dot += (gr[d] * gn) * (cr[d] * sCn[w]);
             dot = wsum(dot) / temp;
-            if (lane == w) mylogit = dot;
+            if (lane == 0) L[w] = dot;
         }
-        const float mx = wmax(mylogit);
-        const float e = lane < W ? expf(mylogit - mx) : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float mx = -INFINITY;
+        for (int w = lane; w < W; w += 64) mx = fmaxf(mx, L[w]);
+        mx = wmax(mx);
+        float e = 0.f;
+        for (int w = lane; w < W; w += 64) e += expf(L[w] - mx);
         const float den = wsum(e);
-        const float a = __shfl(e, wt, 64) / den;
+        const float a = expf(L[wt] - mx) / den;
         if (lane == 0) sA[t] = a;
+        __builtin_amdgcn_wave_barrier();         // L is rewritten for the next frame
     }
     __syncthreads();
     if (wave == 0) {
@@ -194,27 +210,41 @@ __global__ void asd_kernel(const float* __restrict__ q, const float* __restrict_
     float qs = 0.f;
     for (int d = lane; d < D; d += 64) qs += qr[d] * qr[d];
     const float qn = sqrtf(wsum(qs));
-    const int c0 = coff[qi], P = coff[qi + 1] - c0;
-    float best = -INFINITY;
-    int bi = 0;
-    for (int p = 0; p < P && p < 6; ++p) {
-        const float* cr = cand + (long)(c0 + p) * D;
-        float dot = 0.f, cs = 0.f;
-        for (int d = lane; d < D; d += 64) { dot += qr[d] * cr[d]; cs += cr[d] * cr[d]; }
-        dot = wsum(dot);
-        const float cn = sqrtf(wsum(cs));
-        const float sim = dot / fmaxf(qn * cn, 1e-8f) / temp;
-        if (sim > best) { best = sim; bi = p; }
-        if (lane == 0) {
-            if (p == 1) pred[qi * 3 + 0] = bi;
-            if (p == 3) pred[qi * 3 + 1] = bi;
-            if (p == 5) pred[qi * 3 + 2] = bi;
+    const int c0 = coff[qi];
+    int P = coff[qi + 1] - c0;
+    P = P < 6 ? P : 6;
+    float sim[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        sim[p] = -INFINITY;
+        if (p < P) {
+            const float* cr = cand + (long)(c0 + p) * D;
+            float dot = 0.f, cs = 0.f;
+            for (int d = lane; d < D; d += 64) { dot += qr[d] * cr[d]; cs += cr[d] * cr[d]; }
+            dot = wsum(dot);
+            const float cn = sqrtf(wsum(cs));
+            sim[p] = dot / fmaxf(qn * cn, 1e-8f) / temp;
         }
     }
-    if (lane == 0) {
-        if (P < 2) pred[qi * 3 + 0] = bi;
-        if (P < 4) pred[qi * 3 + 1] = bi;
-        if (P < 6) pred[qi * 3 + 2] = bi;
+    // the reference takes np.argmax of softmax(sim[:P']) (evaluate_asd.py:47-49,96-100), P' = min(2|4|6, candidates):
+    // the softmax is evaluated as torch does (exp(x - max) / sum) so that values it rounds together tie the same way
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int np = (2 * k + 2) < P ? (2 * k + 2) : P;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) if (p < np) mx = fmaxf(mx, sim[p]);
+        float e[6], den = 0.f;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) { e[p] = p < np ? expf(sim[p] - mx) : 0.f; den += e[p]; }
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            const float sc = e[p] / den;
+            if (p < np && sc > best) { best = sc; bi = p; }
+        }
+        if (lane == 0) pred[qi * 3 + k] = np > 0 ? bi : -1;
     }
 }
 

@@ -38,12 +38,22 @@ def init_from_env(backend=None):
     td.init_process_group(backend=backend)
 
 
+def _backend():
+    return td.get_backend() if td.is_available() and td.is_initialized() else None
+
+
 def all_gather_rows(x):
     """Gather ragged row blocks (n_r, D) from every rank in rank order.
-    Returns (full (sum n_r, D), row offset of this rank's block)."""
+    Returns (full (sum n_r, D), row offset of this rank's block).
+    nccl (= RCCL over xGMI): one all_gather_into_tensor of the padded blocks, device to device.  gloo (the CPU tests, or
+    several ranks sharing one GPU): device tensors are staged through host memory."""
     ws = world_size()
     if ws == 1:
         return x, 0
+    dev = x.device
+    host_staged = _backend() == "gloo" and x.is_cuda
+    if host_staged:
+        x = x.cpu()
     n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
     counts = [torch.zeros_like(n) for _ in range(ws)]
     td.all_gather(counts, n)
@@ -52,10 +62,13 @@ def all_gather_rows(x):
     pad = torch.zeros((m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     pad[:x.shape[0]] = x
     out = torch.empty((ws * m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    td.all_gather_into_tensor(out, pad) if hasattr(td, "all_gather_into_tensor") and x.is_cuda else \
+    if x.is_cuda and hasattr(td, "all_gather_into_tensor"):
+        td.all_gather_into_tensor(out, pad)
+    else:
         _gather_list(out, pad, ws, m)
     parts = [out[r * m: r * m + counts[r]] for r in range(ws)]
-    return torch.cat(parts, 0), sum(counts[:rank()])
+    full = torch.cat(parts, 0)
+    return (full.to(dev) if host_staged else full), sum(counts[:rank()])
 
 
 def _gather_list(out, pad, ws, m):
@@ -67,7 +80,23 @@ def _gather_list(out, pad, ws, m):
 
 def all_reduce_sum(t):
     if world_size() > 1:
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        if _backend() == "gloo" and t.is_cuda:
+            c = t.cpu()
+            td.all_reduce(c, op=td.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_max(t):
+    if world_size() > 1:
+        if _backend() == "gloo" and t.is_cuda:
+            c = t.cpu()
+            td.all_reduce(c, op=td.ReduceOp.MAX)
+            t.copy_(c)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.MAX)
     return t
 
 

@@ -16,6 +16,10 @@ from ._lib import Engine
 from . import dist as jdist
 
 
+def _tensor(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x, np.float32))
+
+
 def _offsets(mats):
     off = np.zeros(len(mats) + 1, np.int32)
     off[1:] = np.cumsum([m.shape[0] for m in mats])
@@ -44,8 +48,8 @@ def retrieval_metrics(emb1, emb2, engine=None):
     against gallery emb2 (both (N,512), un-normalised video-level means).  Sharded over ranks when
     torch.distributed is initialised: every rank passes ITS contiguous block of rows."""
     eng = engine or Engine.get()
-    e1 = eng.l2norm(torch.as_tensor(np.asarray(emb1, np.float32)) if not isinstance(emb1, torch.Tensor) else emb1)
-    e2 = eng.l2norm(torch.as_tensor(np.asarray(emb2, np.float32)) if not isinstance(emb2, torch.Tensor) else emb2)
+    e1 = eng.l2norm(_tensor(emb1))
+    e2 = eng.l2norm(_tensor(emb2))
     if jdist.world_size() > 1:
         gallery, row_offset = jdist.all_gather_rows(e2)
     else:
@@ -88,7 +92,7 @@ def asd_accuracy(query_content, candidate_gestures, engine=None):
     """evaluate_asd.py:94-113: query_content (N,512) video-level; candidate_gestures = list of (P_i,512)
     with the positive at index 0.  Returns accuracies for 2/4/6 speakers."""
     eng = engine or Engine.get()
-    cand = torch.as_tensor(np.concatenate([np.asarray(c, np.float32) for c in candidate_gestures], 0))
-    pred = eng.asd(torch.as_tensor(np.asarray(query_content, np.float32)), cand, _offsets(candidate_gestures)).cpu().numpy()
+    cand = torch.cat([_tensor(c).to(eng.device) for c in candidate_gestures], 0)
+    pred = eng.asd(_tensor(query_content), cand, _offsets(candidate_gestures)).cpu().numpy()
     n = max(1, pred.shape[0])
     return tuple(float(np.sum(pred[:, k] == 0)) / n for k in range(3))

@@ -204,3 +204,29 @@ def planted_spotting(seed, n_clips, n_frames=150, n_words=30, d=512, noise=1.2):
         bounds.append(wb)
         targets.append(t)
     return gest, cont, bounds, targets
+
+
+def planted_asd(seed, n_queries, d=512, n_frames=12, n_words=5, noise=1.6):
+    """Active-speaker-detection fixture in the shape evaluate_asd.py:54-113 consumes: per query a temporal content
+    embedding (W,d), its own (positive) temporal gesture embedding (T,d) and 0..5 negatives, so candidate lists have
+    P = 1, 3, 5 or 6 entries (the reference slices all_gesture_embs[:2|4|6], shorter lists included).  The positive is
+    the content direction plus `noise`; every third query also gets a HARD negative closer to the content than the
+    positive, so the positive loses in some queries and at different P.  Returns (contents, positives, negatives)."""
+    rng = np.random.default_rng(seed)
+    contents, positives, negatives = [], [], []
+    for i in range(n_queries):
+        base = rng.standard_normal(d).astype(np.float32)
+        base /= np.linalg.norm(base)
+        c = base[None] + np.float32(0.3) * rng.standard_normal((n_words, d)).astype(np.float32) / np.float32(math.sqrt(d))
+        pos = base[None] + np.float32(noise) * rng.standard_normal((n_frames, d)).astype(np.float32) / np.float32(math.sqrt(d))
+        n_neg = (0, 2, 4, 5)[i % 4]
+        negs = []
+        for k in range(n_neg):
+            g = rng.standard_normal((n_frames, d)).astype(np.float32) / np.float32(math.sqrt(d))
+            if i % 3 == 0 and k == (i // 3) % n_neg:
+                g = base[None] + np.float32(0.5 * noise) * g          # hard negative: beats the positive
+            negs.append(g.astype(np.float32))
+        contents.append(c.astype(np.float32))
+        positives.append(pos.astype(np.float32))
+        negatives.append(negs)
+    return contents, positives, negatives

@@ -374,6 +374,27 @@ def similarity_cos(query_emb, data_emb, temp=0.07):
     return torch.softmax(sim / temp, dim=0).numpy()
 
 
+def asd_predictions(query_content, candidates):
+    """Inner loop of evaluate_asd (evaluate_asd.py:94-100): query_content (d,) video-level content embedding,
+    candidates (P,d) video-level gesture embeddings with the positive first -> argmax index for the first 2 / 4 / 6."""
+    q = np.asarray(query_content, np.float32)[None]
+    cand = np.asarray(candidates, np.float32)
+    return [int(np.argmax(similarity_cos(q, cand[:k]))) for k in (2, 4, 6)]
+
+
+def asd_accuracy(contents, positives, negatives):
+    """evaluate_asd (evaluate_asd.py:54-125) on in-memory clips: temporal means (load_feats :26-39), candidate list
+    [positive] + negatives, accuracy = fraction of queries whose argmax is index 0, for 2 / 4 / 6 speakers."""
+    correct = np.zeros(3)
+    preds = []
+    for c, p, negs in zip(contents, positives, negatives):
+        cand = np.stack([np.asarray(p, np.float32).mean(axis=0)] + [np.asarray(g, np.float32).mean(axis=0) for g in negs])
+        pr = asd_predictions(np.asarray(c, np.float32).mean(axis=0), cand)
+        preds.append(pr)
+        correct += np.asarray(pr) == 0
+    return tuple(float(x) / len(contents) for x in correct), np.asarray(preds, np.int32)
+
+
 # --------------------------------------------------------------------------- audio front-end
 
 def wav2filterbanks(wav, mel_basis):

@@ -70,7 +70,51 @@ def _reference_functions(path, names):
     return ns
 
 
+def golden_asd(ea):
+    """(vi-b) ASD at dataset level through the reference's own evaluate_asd(df) (evaluate_asd.py:54-125): 48 queries
+    written as the .pkl files it loads, candidate lists of 1/3/5/6 clips, positives that lose in some queries.  Stored:
+    the per-query argmax of the reference's get_similarity_cos for 2/4/6 speakers and the three counts it prints."""
+    import contextlib
+    import io
+    import pickle
+    import re
+    import tempfile
+
+    import pandas as pd
+    n = 48
+    contents, positives, negatives = synth.planted_asd(9007, n)
+    preds = np.zeros((n, 3), np.int32)
+    with tempfile.TemporaryDirectory() as tmp:
+        rows = []
+        for i in range(n):
+            with open(os.path.join(tmp, f"q{i:03d}__00000.pkl"), "wb") as f:
+                pickle.dump({"gesture_emb": positives[i], "content_emb": contents[i]}, f)
+            negs = []
+            for k, g in enumerate(negatives[i]):
+                with open(os.path.join(tmp, f"q{i:03d}n{k}__00000.pkl"), "wb") as f:
+                    pickle.dump({"gesture_emb": g, "content_emb": None}, f)
+                negs.append(f"q{i:03d}n{k}/00000")
+            rows.append({"filename": f"q{i:03d}/00000", "neg_files": str(negs)})
+            q = torch.FloatTensor(contents[i].mean(axis=0)).unsqueeze(0)
+            allg = torch.cat([torch.FloatTensor(positives[i].mean(axis=0)).unsqueeze(0)] +
+                             [torch.FloatTensor(g.mean(axis=0)).unsqueeze(0) for g in negatives[i]])
+            preds[i] = [int(np.argmax(ea.get_similarity_cos(q, allg[:k]))) for k in (2, 4, 6)]
+        ea.args.path = tmp
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            ea.evaluate_asd(pd.DataFrame(rows))
+    counts = [int(x) for x in re.findall(r"spk: Correct: (\d+) \| Total: 48", buf.getvalue())]
+    assert len(counts) == 3, buf.getvalue()
+    assert counts == [int((preds[:, k] == 0).sum()) for k in range(3)]
+    assert 0 < counts[2] < counts[0] < n, counts          # the positive loses in some queries, more often with more speakers
+    np.savez_compressed(os.path.join(OUT, "asd.npz"), seed=9007, n=n, preds=preds, correct=np.asarray(counts, np.int32))
+    print("asd golden: correct", counts, "of", n)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "asd":           # regenerate only tests/golden/asd.npz
+        golden_asd(_import_eval("evaluate_asd"))
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -156,6 +200,8 @@ def main():
         asd[f"asd{P}"] = ea.get_similarity_cos(q, torch.from_numpy(g_emb[:P]))
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), sim=sim.numpy(), R5=m["R5"], R10=m["R10"], R25=m["R25"],
                         R50=m["R50"], MR=m["MR"], spot_acc=acc, attn0=attn0, **asd)
+
+    golden_asd(ea)
 
     # (vii) text-file grammar: the reference's own load_text on its own sample
     ns = _reference_functions(os.path.join(REF, "inference_embs.py"), {"validate_text_file", "preprocess_text", "load_text"})

@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) == set(declared)
 
 
+def test_hot_kernels_do_not_spill():
+    """the LN-fused GEMM carried 6 VGPR spills (28 B scratch), the 512x128 conv instance 8.  Read
+    .vgpr_spill_count of every kernel from the gfx950 code objects inside libjegal_hip.so so that cannot come back."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    res = kernel_resources()
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("gemm_glds_kernel", "gemm_mlp_kernel", "conv1_direct_kernel", "attn_mfma"))}
+    assert len(hot) >= 10
+    bad = {k: v for k, v in hot.items() if v["spill"] != 0 or v["vgpr"] > 256}
+    assert not bad, bad
+
+
 def test_engine_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
