@@ -490,9 +490,11 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         // u8 HWC video: conv1 + max-pool straight from the frames; neither the temporal stack nor the
         // pre-pool tensor exists in HBM
         f16* edge;
+        unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
+        RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
         RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, p1, edge, h->opts, h->stream); }));
+                                                                   1.0f / 255.0f, p1, edge, zscr, h->opts, h->stream); }));
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -981,9 +983,11 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     const long NF = (long)B * P;
     if (h->conv1_direct) {
         f16* edge;
+        unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
+        RET(wsalloc(h, conv1_zmask_elems(B, T), &zscr));
         return timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, h->opts, h->stream); });
+                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, zscr, h->opts, h->stream); });
     }
     f16 *o1, *S;
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));

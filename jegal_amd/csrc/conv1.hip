@@ -45,6 +45,9 @@ struct Conv1Args {
     float invP;           // 1/P for the position -> (clip, frame) split
     unsigned long long* tl;   // debug timeline (env JG_CONV1_TL): 100 MHz stamps of workgroup 0, waves 0 and 4
     int zskip;            // 1: all-zero input tiles (the face-mask rows) run only the two bias slots
+    const unsigned* zmask;    // [nclip*T] per SOURCE frame: bit rt = input rows 12rt..12rt+15 are all zero (conv1_zero_scan_kernel);
+                              // nullptr: no tile is skipped outright
+    const f16* zconst;        // [64] relu(bias) per channel as fp16: the value of every conv1 output whose patch is all zero
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
                           // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
 };
@@ -68,6 +71,7 @@ constexpr int CARRY_BYTES = 8 * 32 * 16;               // 4096
 constexpr int OFF_CONV = 2 * TILE_BYTES;               // 119808
 constexpr int OFF_CARRY = OFF_CONV + 2 * CONV_BYTES;   // 152576
 constexpr int OFF_INIT = OFF_CARRY + 2 * CARRY_BYTES;  // 160768: int flags[2][4] -- "loader wave w saw a non-zero byte in tile buffer b"
+constexpr int OFF_LIVE = OFF_INIT + 32;                // int live[2] -- "tile buffer b holds a tile" (0 after the workgroup's last tile)
 constexpr int LDS_BYTES = OFF_INIT + 256;              // 161024 <= 163840
 }
 
@@ -100,17 +104,16 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int per = (a.nstrips + 7) >> 3;
     const int r_lo = xcd * per, r_hi = (r_lo + per < a.nstrips) ? r_lo + per : a.nstrips;
     const int s_lo = r_lo + xidx;
-    const int my_strips = (s_lo < r_hi && GX > 0) ? (r_hi - s_lo + GX - 1) / GX : 0;
-    const int ntl = my_strips * ROW_TILES;
-    // local tile t -> (strip, row tile); advanced one tile at a time
-    struct Pos {
+    // Tiles that are skipped OUTRIGHT (zmask, produced by conv1_zero_scan_kernel from the frames): a tile whose 16 input rows are
+    // zero in all 5 frames computes relu(bias) everywhere; if the tile above and the tile below are such tiles too (or do not
+    // exist), both of its pooled rows and its carry are that constant whatever the neighbours hold, so the tile needs no
+    // loads, no barrier slot and no MFMA -- its pooled rows are filled with the constant when the pool waves enter the strip.
+    // Zero tiles NEXT to a non-zero tile still run (2 bias slots, see cvt_write): their pooled rows mix with real data.
+    // The walk below visits the remaining tiles of this workgroup's strips in order; all of it is wave-uniform.
+    struct Walk {
         int strip, rt;
-    };
-    auto advance = [&](Pos& q) {
-        if (++q.rt == ROW_TILES) {
-            q.rt = 0;
-            q.strip += GX;
-        }
+        unsigned skip;      // bit rt: tile rt of `strip` is skipped
+        bool done;
     };
     // strip -> (position nf, column tile j, clip b, padded-clip position p)
     auto decode = [&](int strip, int& nf, int& j, int& b, int& pp) {
@@ -121,6 +124,43 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         if (pp < 0) { --b; pp += a.P; }
         else if (pp >= a.P) { ++b; pp -= a.P; }
     };
+    auto strip_skip = [&](int strip) -> unsigned {
+        if (!a.zmask) return 0u;
+        int nf, j, b, p;
+        decode(strip, nf, j, b, p);
+        unsigned z = 0x3fffffu;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            int f = p + dt - a.pad;
+            f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
+            z &= a.zmask[b * a.T + f];
+        }
+        z = __builtin_amdgcn_readfirstlane(z);
+        return z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+    };
+    // on_strip(strip, skip) is called once for every strip the walk enters (the pool walk fills the skipped tiles there)
+    auto walk_next = [&](Walk& q, auto&& on_strip) {
+        if (q.done) return;
+        while (true) {
+            if (++q.rt == ROW_TILES) {
+                q.rt = 0;
+                q.strip += GX;
+                if (q.strip >= r_hi) { q.done = true; return; }
+                q.skip = strip_skip(q.strip);
+                on_strip(q.strip, q.skip);
+            }
+            if (!((q.skip >> q.rt) & 1u)) return;
+        }
+    };
+    auto walk_first = [&](auto&& on_strip) -> Walk {
+        Walk q = {s_lo, -1, 0u, !(s_lo < r_hi && GX > 0)};
+        if (q.done) return q;
+        q.skip = strip_skip(q.strip);
+        on_strip(q.strip, q.skip);
+        walk_next(q, on_strip);
+        return q;
+    };
+    auto no_fill = [](int, unsigned) {};
 
     if (wave >= 4) {
         // =========================== loader / pool waves ===========================
@@ -130,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const bool has1 = it1 < TROWS * 25;                                // item ltid + 256  (< 400)
         const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
-        auto issue = [&](const Pos& q, C1Regs& R) {
+        auto issue = [&](const Walk& q, C1Regs& R) {
             const int rt = q.rt;
             int nf, j, b, p;
             decode(q.strip, nf, j, b, p);
@@ -221,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
         // fastz: tile t AND the carry above it come from all-zero input tiles, so every conv value involved is the same
         // per-channel constant relu(bias): one LDS read instead of the 3x3 window
-        auto pool = [&](const Pos& q, int t, bool fastz) {
+        auto pool = [&](const Walk& q, int t, bool fastz) {
             const int rt = q.rt;
             const int nf = (int)((unsigned)q.strip / 5u);
             const int j = q.strip - nf * 5;
@@ -266,11 +306,25 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             // carry for the next tile of the strip
             *reinterpret_cast<f16x8*>(cout + (ccg * 32 + ccol) * 16) = cnext;
         };
+        // pooled rows (and edge exports) of the SKIPPED tiles of a strip: the per-channel constant relu(bias).  Same thread
+        // mapping as part A of pool(): one 16-B store per thread and skipped tile, no LDS, no barrier.
+        auto fill_skipped = [&](int strip, unsigned skip) {
+            if (!skip) return;
+            const int nf = (int)((unsigned)strip / 5u);
+            const int j = strip - nf * 5;
+            const f16x8 cz = *reinterpret_cast<const f16x8*>(a.zconst + pcg * 8);
+            const int pw = 16 * j + ppw;
+            for (unsigned m = skip; m; m &= m - 1) {
+                const int rt = __builtin_ctz(m);
+                const int ph = 2 * rt - 1 + prow;
+                if (ph >= 0 && pw < PW)
+                    __builtin_nontemporal_store(cz, reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8));
+                if (ph >= 0 && j > 0 && ppw == 0)
+                    *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = cz;
+            }
+        };
 
-        if (a.dbg & 1) {
-            for (int t = 0; t <= ntl; ++t) __syncthreads();
-            return;
-        }
+        int* live = reinterpret_cast<int*>(smem + OFF_LIVE);
         int tli = 0;
         auto mark = [&]() {
             if (a.tl && blockIdx.x == 0 && wave == 4 && tli < 2000) {
@@ -280,19 +334,36 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             }
         };
         C1Regs RA, RB;
-        Pos qi = {s_lo, 0}, qp = {s_lo, 0};       // next tile to issue loads for; next tile to pool
-        int ti = 0;
+        // walks: qt = tile t of the loop below, qn = tile t+1 (the one whose image is written during iteration t), qi = next
+        // tile to issue loads for (up to t+3), qp = next tile to pool (t-1; entering a strip fills its skipped tiles)
+        Walk qt = walk_first(no_fill);
+        Walk qn = qt;
+        walk_next(qn, no_fill);
+        Walk qi = qt;
         // The frame loads are UNCONDITIONAL (past the end the last tile is simply loaded again): under an
-        // `if (t + 2 < ntl)` the loaded registers become a phi with their old values, hipcc resolves it with
+        // `if (tile t+3 exists)` the loaded registers become a phi with their old values, hipcc resolves it with
         // copies right behind the loads, and every tile waits for its own L2/HBM round trip (1.0-1.4 us of
         // the 3.3 us loader iteration, JG_CONV1_TL=1).
         auto next_i = [&]() {
-            if (ti + 1 < ntl) {
-                ++ti;
-                advance(qi);
-            }
+            Walk nx = qi;
+            walk_next(nx, no_fill);
+            if (!nx.done) qi = nx;
         };
-        if (ntl > 0) {
+        if (a.dbg & 1) {
+            if (ltid == 0) { live[0] = qt.done ? 0 : 1; live[1] = 0; }
+            int t = 0;
+            while (!qt.done) {
+                __syncthreads();
+                if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
+                qt = qn;
+                walk_next(qn, no_fill);
+                ++t;
+            }
+            __syncthreads();
+            return;
+        }
+        if (ltid == 0) { live[0] = qt.done ? 0 : 1; live[1] = 0; }
+        if (!qt.done) {
             issue(qi, RA);                      // tile 0
             next_i();
             cvt_write(RA, smem, 0);
@@ -301,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             issue(qi, RA);                      // tile 2
             next_i();
         }
+        Walk qp = walk_first(fill_skipped);
         // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1.  We
         //   (1) fill tile buffer (t+1)&1 from the registers loaded TWO ITERATIONS ago (zero tiles make an iteration
         //       shorter than an HBM round trip; hipcc waits vmcnt(0) there whenever loads and stores are both pending),
@@ -313,36 +385,51 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const int4 fl = *reinterpret_cast<const int4*>(smem + OFF_INIT + (tt & 1) * 16);
             return __builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) == 0;
         };
+        // fastz for the tile at qp: it is a zero tile and so is the tile above it (the previous tile of the walk, or a skipped
+        // one, or there is none) -- every conv value in its pooling windows is then the per-channel constant
+        auto pool_step = [&](int tprev) {
+            const bool above_zero = qp.rt == 0 || ((qp.skip >> (qp.rt - 1)) & 1u) || z2;
+            pool(qp, tprev, z1 && above_zero);
+            walk_next(qp, fill_skipped);
+        };
         int t = 0;
-        while (t < ntl) {
+        while (!qt.done) {
             mark();
             __syncthreads();
             mark();
             const bool zc0 = tile_is_zero(t);          // before cvt_write reuses the other slot; this slot is rewritten at t+1
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
+            if (!qn.done && !(a.dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
             issue(qi, RB);
             next_i();
             mark();
-            if (t > 0 && !(a.dbg & 4)) { pool(qp, t - 1, z1 && (z2 || qp.rt == 0)); advance(qp); }
+            if (t > 0 && !(a.dbg & 4)) pool_step(t - 1);
             z2 = z1; z1 = zc0;
+            qt = qn;
+            walk_next(qn, no_fill);
             ++t;
-            if (t >= ntl) break;
+            if (qt.done) break;
             mark();
             __syncthreads();
             mark();
             const bool zc1 = tile_is_zero(t);
-            if (t + 1 < ntl && !(a.dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
+            if (!qn.done && !(a.dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
             issue(qi, RA);
             next_i();
             mark();
-            if (!(a.dbg & 4)) { pool(qp, t - 1, z1 && (z2 || qp.rt == 0)); advance(qp); }
+            if (!(a.dbg & 4)) pool_step(t - 1);
             z2 = z1; z1 = zc1;
+            qt = qn;
+            walk_next(qn, no_fill);
             ++t;
         }
         __syncthreads();                       // the MFMA waves have finished the last tile
-        if (ntl > 0 && !(a.dbg & 4)) pool(qp, ntl - 1, z1 && (z2 || qp.rt == 0));
+        if (t > 0 && !(a.dbg & 4)) pool_step(t - 1);
+        // strips after this workgroup's last executed tile may still hold skipped tiles: pool_step's walk_next has entered
+        // (and filled) every remaining strip on its way to `done`
         return;
     }
 
@@ -365,10 +452,12 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             ++tli;
         }
     };
-    for (int t = 0; t < ntl; ++t) {
+    for (int t = 0;; ++t) {
         mark();
         __syncthreads();
         mark();
+        // live[t & 1]: written by the loaders before this barrier; 0 = the workgroup's tiles are done (this was the final barrier)
+        if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + OFF_LIVE + (t & 1) * 4)) == 0) break;
         if (a.dbg & 2) continue;
         const char* cur = smem + (t & 1) * TILE_BYTES;
         char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
@@ -427,7 +516,6 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             epilogue(acc, mb);
         }
     }
-    __syncthreads();                           // hand the last tile's conv rows to the pool waves
 }
 
 // out[nf][ph][16j+15][:] = max(out[...], edge[nf][ph][j][:])  for j = 0..3 (pooled columns 15,31,47,63)
@@ -442,8 +530,55 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
     *reinterpret_cast<f16x8*>(o) = max8(*reinterpret_cast<const f16x8*>(o), e);
 }
 
+// Per source frame: which 16-row input bands (the 22 row tiles of conv1_direct_kernel) are entirely zero.  The reference blanks
+// the face region of every crop (inference_embs.py:264,270); such bands need no conv1 work at all.  One workgroup per frame:
+//   1. probe -- thread r reads 16 B of row r at a row-dependent column: a natural or noisy row is almost surely non-zero
+//      there, so only rows whose probe is zero are read completely (HBM traffic ~ the zero rows + 4 % of the rest),
+//   2. full check of the candidate rows, one wave per row, coalesced 16-B loads,
+//   3. band flags -> 22-bit mask.
+// Block 0 also computes the constant every all-zero patch produces: relu(bias) as the MFMA path rounds it (conv1 bias = the
+// hi+lo pair on the pad lane of slots 0 and 1, times 2^-24; both products and their sum are exact in fp32).
+__global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __restrict__ src, unsigned* __restrict__ zmask,
+                                                              const f16* __restrict__ Wd, float scale, f16* __restrict__ zconst) {
+    __shared__ int rowz[IH + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* fb = src + (size_t)blockIdx.x * (size_t)(IH * IW * 3);
+    for (int r = tid; r < IH; r += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(fb + (size_t)r * (IW * 3) + ((r * 37) % 90) * 16);
+        rowz[r] = (v.x | v.y | v.z | v.w) == 0 ? 1 : 0;
+    }
+    __syncthreads();
+    for (int r = wave; r < IH; r += 4) {
+        if (!rowz[r]) continue;                                      // wave-uniform
+        const uint8_t* row = fb + (size_t)r * (IW * 3);
+        uint4 v = *reinterpret_cast<const uint4*>(row + lane * 16);
+        unsigned nz = v.x | v.y | v.z | v.w;
+        if (lane < 26) {
+            v = *reinterpret_cast<const uint4*>(row + 1024 + lane * 16);
+            nz |= v.x | v.y | v.z | v.w;
+        }
+        if (__builtin_amdgcn_ballot_w64(nz != 0) != 0 && lane == 0) rowz[r] = 0;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bool z = lane < ROW_TILES;
+        if (z) {
+            for (int r = 12 * lane; r < 12 * lane + TROWS; ++r) z = z && (r >= IH || rowz[r]);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(z);
+        if (lane == 0) zmask[blockIdx.x] = (unsigned)m & ((1u << ROW_TILES) - 1u);
+    }
+    if (blockIdx.x == 0 && tid < 64) {
+        const float hi = (float)Wd[(0 * 64 + tid) * 16 + 15], lo = (float)Wd[(1 * 64 + tid) * 16 + 15];
+        const float acc = hi * 5.9604644775390625e-8f + lo * 5.9604644775390625e-8f;          // 2^-24: the pad lane's "1.0"
+        zconst[tid] = (f16)fmaxf(acc * scale, 0.f);
+    }
+}
+
+size_t conv1_zmask_elems(int nclip, int T) { return (size_t)nclip * T + 64; }      // + 64 halves (32 words) for zconst
+
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, const EngineOpts& o, hipStream_t s) {
+                               f16* out_pooled, f16* edge, unsigned* zscratch, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[64] = {};
     if (o.device < 0 || o.device >= 64) return hipErrorInvalidDevice;
     const int num_cu = o.num_cu;
@@ -462,6 +597,15 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     static const int dbg = getenv("JG_CONV1_DBG") ? atoi(getenv("JG_CONV1_DBG")) : 0;
     a.dbg = dbg;
     a.zskip = o.conv1_zero_skip ? 1 : 0;
+    a.zmask = nullptr;
+    a.zconst = nullptr;
+    if (a.zskip && zscratch && nclip * T > 0) {
+        unsigned* zm = zscratch + 32;
+        f16* zc = reinterpret_cast<f16*>(zscratch);
+        hipLaunchKernelGGL(conv1_zero_scan_kernel, dim3((unsigned)(nclip * T)), dim3(256), 0, s, src, zm, Wd, a.scale, zc);
+        a.zmask = zm;
+        a.zconst = zc;
+    }
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
     if (want_tl && !tl && hipHostMalloc(&tl, 4096 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) tl = nullptr;

@@ -66,7 +66,10 @@ def test_jegal_gesture_long_clips(models, oracle_sd, T):
     r0, r1 = rel(out[0], ref[0]), rel(out[1, :valid], ref[1, :valid])
     print(f"T={T}: rel {r0:.3e} / {r1:.3e} (padded clip, valid rows)")
     assert r0 < TOL and r1 < TOL
-    assert rel(out[1], ref[1]) < TOL            # padded query rows are computed by the reference too
+    # The reference also computes the PADDED query rows of clip 1 (zero feature rows; the caller strips them).  Their inputs are
+    # nothing like a clip's (x = 0, where the bias correction (w - fp16(w)).E[x] of the default precision mode is pure error):
+    # they are held to 2e-3, the rows that exist to 1e-3.
+    assert rel(out[1], ref[1]) < 2e-3
 
 
 @pytest.mark.parametrize("L", [33, 70, 200])
@@ -145,6 +148,41 @@ def test_precision_w2_all(option_case):
     e.close()
     print("W2_ALL rel", err)
     assert err < TOL
+
+
+def test_conv1_zero_band_skip_is_bit_identical(engine, models):
+    """conv1 skips input tiles that conv1_zero_scan_kernel finds all-zero (bands of 16 rows, all 5 frames of a position).
+    Skipping must never change a bit.  Patterns: the reference's face mask (zero prefix), no zero row at all, zero bands in
+    the middle and at the bottom, whole black frames (fully skipped strips), black clips next to normal ones, and a single
+    non-zero byte hidden in an otherwise black band (defeats the 16-byte probe, caught by the full row check)."""
+    rng = np.random.default_rng(77)
+    T = 9
+    clips = rng.integers(0, 256, (6, T, 270, 480, 3), dtype=np.uint8)
+    clips[0, :, :110] = 0                                   # face mask
+    clips[2, :, 60:150] = 0                                 # band in the middle
+    clips[2, :, 230:] = 0                                   # ... and the bottom
+    clips[3] = 0                                            # black clip
+    clips[3, 4, 135, 7, 1] = 3                              # one byte in one frame
+    clips[4, :, :200] = 0
+    clips[4, 2:5] = 0                                       # black frames inside a masked clip
+    clips[5, :, :110] = 0
+    clips[5, 6, 50, 479, 2] = 255                           # last byte of a row inside the mask
+    frames = torch.from_numpy(clips).cuda()
+    engine.set_option("conv1_zero_skip", 0)
+    try:
+        ref = engine.debug_conv1_pool(frames, 4).clone()
+    finally:
+        engine.set_option("conv1_zero_skip", 1)
+    out = engine.debug_conv1_pool(frames, 4)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, ref)
+    # and against the stack + implicit-GEMM formulation (independent kernels): same fp16 operands, fp32 sums in another order
+    engine.set_option("conv1_direct", 0)
+    try:
+        alt = engine.debug_conv1_pool(frames, 4)
+    finally:
+        engine.set_option("conv1_direct", 1)
+    assert rel(out.float(), alt.float()) < 3e-4
 
 
 # ------------------------------------------------------------------ (d) bias correction calibrated on the wrong data
