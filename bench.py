@@ -284,7 +284,7 @@ def main():
         traffic, traffic_note = load_traffic()
         exec_gflop_clip = CONV1_GFLOP_PER_CLIP * exec_frac + CONV_REST_GFLOP_PER_CLIP + LINEAR_GFLOP_PER_CLIP
         stage = {k: v[0] / nprof for k, v in prof.items()}
-        conv_ms = stage["conv1"] + stage["maxpool"] + stage["conv2-fc6+audio_cnn"] + stage["stack_frames"]
+        conv_ms = stage["conv1"] + stage["conv1_aux"] + stage["maxpool"] + stage["conv2-fc6+audio_cnn"] + stage["stack_frames"]
         lin_ms = stage["gemm"] + stage["attention"] + stage["layernorm"]
         res = {
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",

@@ -466,6 +466,16 @@ ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int P
 // ------------------------------------------------------------------------------------ GestSync
 constexpr int FH = 270, FW = 480;
 
+// conv1 + max-pool straight from u8 frames: zero-band scan (stage "conv1_aux"), the fused kernel (stage "conv1": the
+// path's dominant kernel, timed alone), strip-seam fix-up (stage "conv1_aux")
+int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pad, f16* pooled, f16* edge, unsigned* zscr) {
+    const bool scan = h->opts.conv1_zero_skip;
+    if (scan) RET(timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv1_scan(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, zscr, h->stream); }));
+    RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, pooled, edge,
+                                                               scan ? zscr : nullptr, h->opts, h->stream); }));
+    return timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv1_edge_fix(pooled, edge, (long)nclip * (T + 2 * pad - 4), h->stream); });
+}
+
 // conv stack over `nclip` temporal volumes -> conv_out (nclip*P, 512) fp32, P = T + 2*pad - 4
 int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, long sh, long sw, long sc,
                   int nclip, int T, int pad, float* conv_out) {
@@ -493,8 +503,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
-        RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(src), nclip, T, pad, h->c1_direct,
-                                                                   1.0f / 255.0f, p1, edge, zscr, h->opts, h->stream); }));
+        RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr));
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -520,7 +529,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
 // All twelve projections must qualify (single-fp16 weights, not the calibration pass): the fused kernel keeps the
 // fp32 residual stream in its own tiled order (gemm.hip), so fused and unfused layers cannot be mixed.
 bool gs_fused_plan(const jg_handle* h, int M) {
-    if (!h->fuse_ln || h->calib || M < 1024) return false;
+    if (!h->fuse_ln || !h->opts.gemm_glds || h->calib || M < 1024) return false;      // the tiled token stream is read by LDS-DMA only
     for (int l = 0; l < 6; ++l)
         if (h->gs_layers[l].out.wl || h->gs_layers[l].ff2.wl) return false;
     return true;
@@ -843,7 +852,7 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
 extern "C" {
 
 const char* jg_stage_name(int s) {
-    static const char* n[] = {"stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc"};
+    static const char* n[] = {"stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc", "conv1_aux"};
     return (s >= 0 && s < JG_ST_COUNT) ? n[s] : "?";
 }
 
@@ -986,8 +995,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(B, T), &zscr));
-        return timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(static_cast<const uint8_t*>(frames_u8), B, T, pad, h->c1_direct,
-                                                                      1.0f / 255.0f, static_cast<f16*>(out_f16), edge, zscr, h->opts, h->stream); });
+        return conv1_from_frames(h, static_cast<const uint8_t*>(frames_u8), B, T, pad, static_cast<f16*>(out_f16), edge, zscr);
     }
     f16 *o1, *S;
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));

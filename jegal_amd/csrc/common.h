@@ -126,9 +126,12 @@ hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);
-// zscratch: conv1_zmask_elems(nclip, T) 32-bit words of workspace for the zero-band scan (nullptr: no tile is skipped outright)
+// conv1 from u8 frames = three launches: launch_conv1_scan (zero bands -> skip masks, into zscratch: conv1_zmask_elems words),
+// launch_conv1_direct (zscratch == nullptr: nothing is skipped), launch_conv1_edge_fix (pooled columns that straddle two strips)
+hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale, unsigned* zscratch, hipStream_t s);
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, unsigned* zscratch, const EngineOpts& o, hipStream_t s);
+                               f16* out_pooled, f16* edge, const unsigned* zscratch, const EngineOpts& o, hipStream_t s);
+hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long positions, hipStream_t s);
 size_t conv1_zmask_elems(int nclip, int T);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);

@@ -41,12 +41,13 @@ struct Conv1Args {
     float scale;          // uniform epilogue scale (1/255 for u8 sources; BN scale is folded into Wd)
     f16* out;             // pooled [nclip*P][43][78][64]
     f16* edge;            // [nclip*P][43][4][64]: vertically pooled conv column 32*j (j=1..4)
+    f16* dump;            // [gridDim.x][256][8]: scratch slots for stores of lanes that have no output (behind `edge`)
     int nstrips;          // nclip * P * 5
     float invP;           // 1/P for the position -> (clip, frame) split
     unsigned long long* tl;   // debug timeline (env JG_CONV1_TL): 100 MHz stamps of workgroup 0, waves 0 and 4
     int zskip;            // 1: all-zero input tiles (the face-mask rows) run only the two bias slots
-    const unsigned* zmask;    // [nclip*T] per SOURCE frame: bit rt = input rows 12rt..12rt+15 are all zero (conv1_zero_scan_kernel);
-                              // nullptr: no tile is skipped outright
+    const unsigned* zmask;    // [nclip*P] per POSITION: bit rt = tile rt of the position's 5 strips is skipped outright
+                              // (conv1_zero_scan_kernel + conv1_skip_mask_kernel); nullptr: no tile is skipped
     const f16* zconst;        // [64] relu(bias) per channel as fp16: the value of every conv1 output whose patch is all zero
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
                           // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
@@ -72,16 +73,26 @@ constexpr int OFF_CONV = 2 * TILE_BYTES;               // 119808
 constexpr int OFF_CARRY = OFF_CONV + 2 * CONV_BYTES;   // 152576
 constexpr int OFF_INIT = OFF_CARRY + 2 * CARRY_BYTES;  // 160768: int flags[2][4] -- "loader wave w saw a non-zero byte in tile buffer b"
 constexpr int OFF_LIVE = OFF_INIT + 32;                // int live[2] -- "tile buffer b holds a tile" (0 after the workgroup's last tile)
-constexpr int LDS_BYTES = OFF_INIT + 256;              // 161024 <= 163840
+constexpr int OFF_SKIP = OFF_INIT + 256;               // unsigned skip[MAX_WG_STRIPS]: skip mask of this workgroup's k-th strip
+constexpr int MAX_WG_STRIPS = 640;
+constexpr int LDS_BYTES = OFF_SKIP + 4 * MAX_WG_STRIPS;   // 163584 <= 163840
+constexpr int MAX_WGS = 1024;
+constexpr int DUMP_HALVES_PER_WG = 256 * 8;            // one 16-B slot per loader thread for stores that have nowhere to go
 }
 
-struct C1Regs { uint32_t w[2][5][3]; };     // two (row, 4-pixel group) items x 5 frames x 12 bytes
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+struct C1Regs { u32x3 w[2][5]; };           // two (row, 4-pixel group) items x 5 frames x 12 bytes
 
 __device__ __forceinline__ f16x8 max8(f16x8 a, f16x8 b) {
     return __builtin_elementwise_max(a, b);            // 4 x v_pk_max_f16
 }
 
+// DBG: the timeline stamps (JG_CONV1_TL) and the ablation switches (JG_CONV1_DBG) exist only in the <true> instantiation: in the
+// loader waves every extra scalar compare-and-branch per tile is on the critical path (one wave per SIMD, ~9 cycles per
+// instruction next to the MFMA wave).
+template <bool DBG>
 __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
+    const int dbg = DBG ? a.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // The walk below visits the remaining tiles of this workgroup's strips in order; all of it is wave-uniform.
     struct Walk {
         int strip, rt;
+        int k;              // strip = s_lo + k * GX: index into the workgroup's skip table in LDS
         unsigned skip;      // bit rt: tile rt of `strip` is skipped
         bool done;
     };
@@ -124,19 +136,12 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         if (pp < 0) { --b; pp += a.P; }
         else if (pp >= a.P) { ++b; pp -= a.P; }
     };
-    auto strip_skip = [&](int strip) -> unsigned {
-        if (!a.zmask) return 0u;
-        int nf, j, b, p;
-        decode(strip, nf, j, b, p);
-        unsigned z = 0x3fffffu;
-#pragma unroll
-        for (int dt = 0; dt < 5; ++dt) {
-            int f = p + dt - a.pad;
-            f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
-            z &= a.zmask[b * a.T + f];
-        }
-        z = __builtin_amdgcn_readfirstlane(z);
-        return z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+    // The skip masks of this workgroup's strips sit in LDS (filled below, before the roles split): a global load inside the
+    // walks would put an s_waitcnt vmcnt(0) -- hipcc cannot count across the walks' loops -- behind every batch of frame loads.
+    const unsigned* skip_tab = reinterpret_cast<const unsigned*>(smem + OFF_SKIP);
+    const bool use_skip = a.zmask != nullptr;
+    auto strip_skip = [&](int k) -> unsigned {
+        return use_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip_tab[k]) : 0u;
     };
     // on_strip(strip, skip) is called once for every strip the walk enters (the pool walk fills the skipped tiles there)
     auto walk_next = [&](Walk& q, auto&& on_strip) {
@@ -145,23 +150,32 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             if (++q.rt == ROW_TILES) {
                 q.rt = 0;
                 q.strip += GX;
+                ++q.k;
                 if (q.strip >= r_hi) { q.done = true; return; }
-                q.skip = strip_skip(q.strip);
+                q.skip = strip_skip(q.k);
                 on_strip(q.strip, q.skip);
             }
             if (!((q.skip >> q.rt) & 1u)) return;
         }
     };
     auto walk_first = [&](auto&& on_strip) -> Walk {
-        Walk q = {s_lo, -1, 0u, !(s_lo < r_hi && GX > 0)};
+        Walk q = {s_lo, -1, 0, 0u, !(s_lo < r_hi && GX > 0)};
         if (q.done) return q;
-        q.skip = strip_skip(q.strip);
+        q.skip = strip_skip(0);
         on_strip(q.strip, q.skip);
         walk_next(q, on_strip);
         return q;
     };
     auto no_fill = [](int, unsigned) {};
 
+    if (use_skip) {
+        unsigned* tab = reinterpret_cast<unsigned*>(smem + OFF_SKIP);
+        for (int k = tid; k < MAX_WG_STRIPS; k += 512) {
+            const int strip = s_lo + k * GX;
+            tab[k] = strip < r_hi ? a.zmask[(unsigned)strip / 5u] : 0u;
+        }
+        __syncthreads();
+    }
     if (wave >= 4) {
         // =========================== loader / pool waves ===========================
         const int ltid = tid - 256;
@@ -170,36 +184,59 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         const bool has1 = it1 < TROWS * 25;                                // item ltid + 256  (< 400)
         const int row1 = has1 ? it1 / 25 : 0, g1 = has1 ? it1 - row1 * 25 : 0;
 
-        auto issue = [&](const Walk& q, C1Regs& R) {
-            const int rt = q.rt;
+        // ---- frame loads.  Everything that depends only on the STRIP is computed when the issue walk enters it (strip_setup):
+        // the wave-uniform base of the position's first frame, the byte distance of its other four frames (frames are clamped
+        // at the clip's ends, inference_embs.py:283) and the per-lane byte offset of the two items at row tile 0.  Per tile that
+        // leaves one scalar add per frame and one vector add per item.
+        // (kept in SGPRs by construction -- readfirstlane at the point of definition -- so that the per-tile address arithmetic
+        // is scalar and the loads' base registers are SALU-written: a VALU-written SGPR needs 5 wait states before a VMEM
+        // instruction may read it, and hipcc pads nothing for the operands of an asm statement)
+        uint32_t fb0_lo = (uint32_t)(uintptr_t)a.src, fb0_hi = (uint32_t)((uintptr_t)a.src >> 32);   // frame clamp(p - pad) of the issue walk's strip
+        uint32_t fdelta[5] = {0, 0, 0, 0, 0};       // byte distance of frame dt from it
+        uint32_t ioff[2] = {0, 0};                  // per lane: ((row_u) * IW + px_u) * 3 for the strip's column tile
+        auto strip_setup = [&](int strip) {
             int nf, j, b, p;
-            decode(q.strip, nf, j, b, p);
-            // per-lane byte offsets inside a frame (the same for the 5 frames); the frame base is wave-uniform, so
-            // each load is `global_load_dwordx3 v, v_off, s[base]` with no per-load address arithmetic.
-            // UNCONDITIONAL loads from a clamped address: a `cond ? load : 0` select makes hipcc branch
-            // around every load and wait vmcnt(0) after it (10 serial L2 round trips per tile).
-            // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never used.
-            uint32_t off[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int row = u ? row1 : row0, g = u ? g1 : g0;
-                int ih = rt * 12 + row, px = j * 96 + 4 * g;
-                ih = ih < IH ? ih : IH - 1;
-                px = px < IW ? px : IW - 4;
-                off[u] = (uint32_t)((ih * IW + px) * 3);
-            }
+            decode(strip, nf, j, b, p);
+            int f0 = p - a.pad;
+            f0 = f0 < 0 ? 0 : (f0 > a.T - 1 ? a.T - 1 : f0);
+            const uintptr_t fb = (uintptr_t)(a.src + (size_t)(b * a.T + f0) * (size_t)(IH * IW * 3));
+            fb0_lo = __builtin_amdgcn_readfirstlane((uint32_t)fb);
+            fb0_hi = __builtin_amdgcn_readfirstlane((uint32_t)(fb >> 32));
 #pragma unroll
             for (int dt = 0; dt < 5; ++dt) {
                 int f = p + dt - a.pad;
                 f = f < 0 ? 0 : (f > a.T - 1 ? a.T - 1 : f);
-                const uint8_t* fb = a.src + (size_t)(b * a.T + f) * (size_t)(IH * IW * 3);
+                fdelta[dt] = __builtin_amdgcn_readfirstlane((uint32_t)(f - f0) * (uint32_t)(IH * IW * 3));
+            }
+            // Pixels >= 480 (strip 4) only feed conv columns 158/159, which are never used: clamp the group to the last one
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const uint32_t* s = reinterpret_cast<const uint32_t*>(fb + off[u]);
-                    R.w[u][dt][0] = s[0];
-                    R.w[u][dt][1] = s[1];
-                    R.w[u][dt][2] = s[2];
+            for (int u = 0; u < 2; ++u) {
+                const int row = u ? row1 : row0, g = u ? g1 : g0;
+                int px = j * 96 + 4 * g;
+                px = px < IW ? px : IW - 4;
+                ioff[u] = (uint32_t)((row * IW + px) * 3);
+            }
+        };
+        // Input rows 12*rt + row <= 267 < 270: no row clamp.  UNCONDITIONAL loads (a `cond ? load : 0` select makes hipcc
+        // branch around every load); inline asm on purpose: hipcc must neither count nor wait for them.  Left to the compiler,
+        // the wait in front of cvt_write() is vmcnt(10) -- it cannot count the pool stores behind branches and the other register
+        // set's loads across the loop edge -- i.e. every iteration also waited for the pooled-row STORES issued just before the
+        // barrier.  wait_frames() below counts by hand.
+        auto issue = [&](int rt, C1Regs& R) {
+            const uint32_t roff = (uint32_t)rt * (uint32_t)(12 * IW * 3);
+            const uint32_t o0 = ioff[0] + roff, o1 = ioff[1] + roff;
+#pragma unroll
+            for (int dt = 0; dt < 5; ++dt) {
+                const uint8_t* fbu = reinterpret_cast<const uint8_t*>(((uintptr_t)fb0_lo | ((uintptr_t)fb0_hi << 32)) + fdelta[dt]);
+                // s_nop 4: the base may come straight out of a v_readfirstlane, and hipcc pads no hazard for an operand of an asm
+                // statement (VALU-written SGPR -> VMEM address: 5 wait states; cdna_hip_programming.md 5.7 item 2)
+                if (DBG && (dbg & 32)) {            // debugging aid: compiler-visible loads
+                    R.w[0][dt] = *reinterpret_cast<const u32x3*>(fbu + o0);
+                    R.w[1][dt] = *reinterpret_cast<const u32x3*>(fbu + o1);
+                    continue;
                 }
+                asm volatile("s_nop 4\n\tglobal_load_dwordx3 %0, %1, %2" : "=v"(R.w[0][dt]) : "v"(o0), "s"(fbu) : "memory");
+                asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(R.w[1][dt]) : "v"(o1), "s"(fbu) : "memory");
             }
         };
         // u8 -> fp16 WITHOUT arithmetic: byte n zero-extended to 16 bits IS the fp16 subnormal n * 2^-24, exact for
@@ -213,6 +250,22 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // ~40 % of the crop).  A tile whose 16 x 100 x 5 source pixels are all zero contributes nothing but the bias
         // slots: the MFMA waves then run 2 of the 49 slots (bit-identical: the other 47 add exact zeros), and a tile
         // buffer that already holds a zero image is not rewritten.  Decided per tile from the bytes just loaded.
+        // Counted wait for the frame loads of register set R (issued two iterations ago), by hand (see issue()).  Program order of
+        // this wave's VMEM operations per iteration: pooled-row stores (>= 1: pool() issues its output store unconditionally),
+        // then the ten loads of one set.  Younger than R's loads are therefore the stores of the last iteration and the OTHER set's
+        // loads: vmcnt(11) retires R and leaves those in flight; the stores of THIS iteration are issued behind the wait.
+        // Further stores (edge exports, skipped-tile fills) only make the wait retire R earlier than needed, never later than
+        // safe.  The first two iterations have no store behind R: vmcnt(10); the prologue's first tile: vmcnt(0).  The empty asm
+        // makes the registers opaque so that no consumer is scheduled above the wait (cdna_hip_programming.md 5.7).
+        auto wait_frames = [&](C1Regs& R, int level) {
+            if (level == 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else if (level == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) asm volatile("" : "+v"(R.w[u][dt]));
+        };
         bool zero_image[2] = {false, false};       // this wave's part of tile buffer b currently holds an all-zero tile
         int* flags = reinterpret_cast<int*>(smem + OFF_INIT);
         auto cvt_write = [&](const C1Regs& R, char* buf, int slot) {
@@ -257,14 +310,19 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // pooling of local tile t (its conv rows are in conv buffer t&1):
         //   pooled row 2rt-1 = hpool(max(carry, R0)),  pooled row 2rt = hpool(max(R0,R1,R2)),  carry' = max(R2,R3)
         const int pcg = (ltid >> 4) & 7, ppw = ltid & 15;                         // part A: 2 x 8 x 16 threads
+        f16* const dump = a.dump + ((long)blockIdx.x * 256 + ltid) * 8;
+        // relu(bias) of this thread's 8 channels: what every conv1 output over an all-zero patch is (loaded once: no global
+        // load may sit inside the tile loop, see wait_frames)
+        const f16x8 cz = use_skip ? *reinterpret_cast<const f16x8*>(a.zconst + pcg * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         const int prow = __builtin_amdgcn_readfirstlane(ltid >> 7);               // wave-uniform: waves 4,5 / 6,7
         const int ccol = ltid & 31, ccg = ltid >> 5;                              // part C: 8 x 32 threads
         // fastz: tile t AND the carry above it come from all-zero input tiles, so every conv value involved is the same
         // per-channel constant relu(bias): one LDS read instead of the 3x3 window
-        auto pool = [&](const Walk& q, int t, bool fastz) {
-            const int rt = q.rt;
-            const int nf = (int)((unsigned)q.strip / 5u);
-            const int j = q.strip - nf * 5;
+        // per-thread part of the output address (halves): pooled row prow, pooled column ppw, channel group pcg
+        const int pthr = (prow * PW + ppw) * 64 + pcg * 8;
+        auto pool = [&](int strip, int rt, int t, bool fastz) {
+            const int nf = (int)((unsigned)strip / 5u);
+            const int j = strip - nf * 5;
             const char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
             const char* cin = smem + OFF_CARRY + ((rt & 1) ^ 1) * CARRY_BYTES;
             char* cout = smem + OFF_CARRY + (rt & 1) * CARRY_BYTES;
@@ -294,8 +352,14 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             }
             const int ph = 2 * rt - 1 + prow;
             const int pw = 16 * j + ppw;
-            if (ph >= 0 && pw < PW)
-                __builtin_nontemporal_store(m, reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8));   // streamed: keep the frames in L2
+            // ONE store per pool() call and wave whatever the lanes hold (wait_frames counts on it): lanes without an output
+            // (pooled row -1 of the top tile, pooled columns >= 78 of the last strip) write their slot of a dump area instead.
+            // Address = wave-uniform 64-bit part (position, pooled row 2rt-1, column tile) + the per-thread constant.
+            {
+                const long ub = ((long)nf * PH + (2 * rt - 1)) * (PW * 64) + j * (16 * 64);
+                f16* dst = (ph >= 0 && pw < PW) ? a.out + ub + pthr : dump;
+                __builtin_nontemporal_store(m, reinterpret_cast<f16x8*>(dst));       // streamed: keep the frames in L2
+            }
             if (ph >= 0 && j > 0 && ppw == 0) {     // export conv column 0 (vertically pooled) for strip j-1's last pooled column
                 f16x8 e;
                 if (fastz) e = m;
@@ -312,7 +376,6 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             if (!skip) return;
             const int nf = (int)((unsigned)strip / 5u);
             const int j = strip - nf * 5;
-            const f16x8 cz = *reinterpret_cast<const f16x8*>(a.zconst + pcg * 8);
             const int pw = 16 * j + ppw;
             for (unsigned m = skip; m; m &= m - 1) {
                 const int rt = __builtin_ctz(m);
@@ -327,55 +390,62 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         int* live = reinterpret_cast<int*>(smem + OFF_LIVE);
         int tli = 0;
         auto mark = [&]() {
-            if (a.tl && blockIdx.x == 0 && wave == 4 && tli < 2000) {
+            if (DBG && a.tl && blockIdx.x == 0 && wave == 4 && tli < 2000) {
                 const unsigned long long c = wall_clock64();
                 if (lane == 0) a.tl[2048 + tli] = c;
                 ++tli;
             }
         };
         C1Regs RA, RB;
-        // walks: qt = tile t of the loop below, qn = tile t+1 (the one whose image is written during iteration t), qi = next
-        // tile to issue loads for (up to t+3), qp = next tile to pool (t-1; entering a strip fills its skipped tiles)
-        Walk qt = walk_first(no_fill);
-        Walk qn = qt;
-        walk_next(qn, no_fill);
-        Walk qi = qt;
-        // The frame loads are UNCONDITIONAL (past the end the last tile is simply loaded again): under an
-        // `if (tile t+3 exists)` the loaded registers become a phi with their old values, hipcc resolves it with
-        // copies right behind the loads, and every tile waits for its own L2/HBM round trip (1.0-1.4 us of
-        // the 3.3 us loader iteration, JG_CONV1_TL=1).
-        auto next_i = [&]() {
-            Walk nx = qi;
-            walk_next(nx, no_fill);
-            if (!nx.done) qi = nx;
+        // ONE walk, the issue walk (it runs three tiles ahead of the loop); the tiles the other steps of an iteration work on are
+        // its last positions, kept in a small history: hA = tile t+2, hB = t+1 (image written this iteration), hC = t (the
+        // MFMA waves' tile), hD = t-1 (pooled this iteration).  Entering a strip (on_strip) sets up its frame addressing and
+        // fills its skipped tiles with the constant -- those stores touch no other tile's rows, so they can go at any time.
+        struct Hist { int strip, rt; unsigned skip; bool done; };
+        auto on_strip = [&](int strip, unsigned skip) {
+            strip_setup(strip);
+            fill_skipped(strip, skip);
         };
-        if (a.dbg & 1) {
-            if (ltid == 0) { live[0] = qt.done ? 0 : 1; live[1] = 0; }
+        Walk qi = walk_first(on_strip);
+        auto hist = [](const Walk& q) { return Hist{q.strip, q.rt, q.skip, q.done}; };
+        const Hist none = {0, 0, 0u, true};
+        Hist hA = none, hB = none, hC = none, hD = none;
+        // issue the frame loads of the walk's tile and advance it.  The loads are UNCONDITIONAL (past the end the last tile is
+        // simply loaded again: under an `if` the loaded registers become a phi with their old values and hipcc resolves it with
+        // copies right behind the loads); the history still records `done`.
+        int last_rt = 0;
+        auto issue_next = [&](C1Regs& R) {
+            hD = hC; hC = hB; hB = hA;
+            hA = hist(qi);
+            if (!qi.done) last_rt = qi.rt;
+            issue(last_rt, R);
+            // the strip state (fb0, fdelta, ioff) must stay that of the LAST tile once the walk is done: walk_next() only calls
+            // on_strip() for a strip that exists
+            walk_next(qi, on_strip);
+        };
+        if (ltid == 0) { live[0] = qi.done ? 0 : 1; live[1] = 0; }
+        if (DBG && (dbg & 1)) {
+            Walk q = qi;
             int t = 0;
-            while (!qt.done) {
+            while (!q.done) {
                 __syncthreads();
-                if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
-                qt = qn;
-                walk_next(qn, no_fill);
+                walk_next(q, no_fill);
+                if (ltid == 0) live[(t + 1) & 1] = q.done ? 0 : 1;
                 ++t;
             }
             __syncthreads();
             return;
         }
-        if (ltid == 0) { live[0] = qt.done ? 0 : 1; live[1] = 0; }
-        if (!qt.done) {
-            issue(qi, RA);                      // tile 0
-            next_i();
+        const bool any_tile = !qi.done;
+        issue_next(RA);                         // tile 0 (or nothing: the loads are harmless)
+        if (any_tile) {
+            wait_frames(RA, 0);
             cvt_write(RA, smem, 0);
-            issue(qi, RB);                      // tile 1
-            next_i();
-            issue(qi, RA);                      // tile 2
-            next_i();
         }
-        Walk qp = walk_first(fill_skipped);
+        issue_next(RB);                         // tile 1
+        issue_next(RA);                         // tile 2        now hA = 2, hB = 1, hC = 0
         // iteration t: after the barrier the MFMA waves read tile buffer t&1 and write conv buffer t&1.  We
-        //   (1) fill tile buffer (t+1)&1 from the registers loaded TWO ITERATIONS ago (zero tiles make an iteration
-        //       shorter than an HBM round trip; hipcc waits vmcnt(0) there whenever loads and stores are both pending),
+        //   (1) fill tile buffer (t+1)&1 from the registers loaded TWO ITERATIONS ago,
         //   (2) reload the same registers with tile t+3,
         //   (3) pool tile t-1 (its stores go last).
         // Two register sets, so the loop is unrolled by two (a runtime-selected set would be a phi again).
@@ -385,51 +455,48 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const int4 fl = *reinterpret_cast<const int4*>(smem + OFF_INIT + (tt & 1) * 16);
             return __builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) == 0;
         };
-        // fastz for the tile at qp: it is a zero tile and so is the tile above it (the previous tile of the walk, or a skipped
+        // fastz for the tile hD: it is a zero tile and so is the tile above it (the previous tile of the walk, or a skipped
         // one, or there is none) -- every conv value in its pooling windows is then the per-channel constant
         auto pool_step = [&](int tprev) {
-            const bool above_zero = qp.rt == 0 || ((qp.skip >> (qp.rt - 1)) & 1u) || z2;
-            pool(qp, tprev, z1 && above_zero);
-            walk_next(qp, fill_skipped);
+            const bool above_zero = hD.rt == 0 || ((hD.skip >> (hD.rt - 1)) & 1u) || z2;
+            pool(hD.strip, hD.rt, tprev, z1 && above_zero);
         };
         int t = 0;
-        while (!qt.done) {
+        while (!hC.done) {                      // hC = tile t
             mark();
             __syncthreads();
             mark();
             const bool zc0 = tile_is_zero(t);          // before cvt_write reuses the other slot; this slot is rewritten at t+1
-            if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
-            if (!qn.done && !(a.dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (ltid == 0) live[(t + 1) & 1] = hB.done ? 0 : 1;
+            wait_frames(RB, (t >= 2 && !dbg) ? 2 : 1);
+            if (!hB.done && !(dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
-            issue(qi, RB);
-            next_i();
+            if (t > 0 && !(dbg & 4)) pool_step(t - 1);          // hD = tile t-1; its stores go BEFORE the loads (wait_frames)
             mark();
-            if (t > 0 && !(a.dbg & 4)) pool_step(t - 1);
+            issue_next(RB);                     // tile t+3; the history shifts: hC = t+1, hD = t
             z2 = z1; z1 = zc0;
-            qt = qn;
-            walk_next(qn, no_fill);
             ++t;
-            if (qt.done) break;
+            if (hC.done) break;
             mark();
             __syncthreads();
             mark();
             const bool zc1 = tile_is_zero(t);
-            if (ltid == 0) live[(t + 1) & 1] = qn.done ? 0 : 1;
-            if (!qn.done && !(a.dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (ltid == 0) live[(t + 1) & 1] = hB.done ? 0 : 1;
+            wait_frames(RA, (t >= 2 && !dbg) ? 2 : 1);
+            if (!hB.done && !(dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
             mark();
-            issue(qi, RA);
-            next_i();
+            if (!(dbg & 4)) pool_step(t - 1);
             mark();
-            if (!(a.dbg & 4)) pool_step(t - 1);
+            issue_next(RA);
             z2 = z1; z1 = zc1;
-            qt = qn;
-            walk_next(qn, no_fill);
             ++t;
         }
-        __syncthreads();                       // the MFMA waves have finished the last tile
-        if (t > 0 && !(a.dbg & 4)) pool_step(t - 1);
-        // strips after this workgroup's last executed tile may still hold skipped tiles: pool_step's walk_next has entered
-        // (and filled) every remaining strip on its way to `done`
+        // The last frame loads (re-loads of the final tile) are never consumed: their registers are dead from here on and hipcc,
+        // which does not know the asm loads are in flight, is free to reuse them -- a late return would then overwrite an address
+        // of the final pool().  Drain them first.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // the MFMA waves have finished the last tile (hD = tile t-1)
+        if (t > 0 && !(dbg & 4)) pool_step(t - 1);
         return;
     }
 
@@ -446,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     constexpr int DEPTH = 6;                             // patch fragments in flight per wave
     int tli = 0;
     auto mark = [&]() {
-        if (a.tl && blockIdx.x == 0 && wave == 0 && tli < 2000) {
+        if (DBG && a.tl && blockIdx.x == 0 && wave == 0 && tli < 2000) {
             const unsigned long long c = wall_clock64();
             if (lane == 0) a.tl[tli] = c;
             ++tli;
@@ -458,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         mark();
         // live[t & 1]: written by the loaders before this barrier; 0 = the workgroup's tiles are done (this was the final barrier)
         if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem + OFF_LIVE + (t & 1) * 4)) == 0) break;
-        if (a.dbg & 2) continue;
+        if (dbg & 2) continue;
         const char* cur = smem + (t & 1) * TILE_BYTES;
         char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
         // The two blocks of a tile form ONE stream of 98 (block, slot) steps with DEPTH fragments in
@@ -575,21 +642,56 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
     }
 }
 
-size_t conv1_zmask_elems(int nclip, int T) { return (size_t)nclip * T + 64; }      // + 64 halves (32 words) for zconst
+// position nf = (clip b, padded-clip position p) reads frames clamp(p + dt - pad), dt = 0..4: a tile is all-zero for the position
+// when its band is zero in all five; it is SKIPPED when the tiles above and below are all-zero too (or do not exist), so that
+// both of its pooled rows and its carry are the constant whatever the neighbours hold.
+__global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip) {
+    const int nf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nf >= nclip * P) return;
+    const int b = nf / P, p = nf - b * P;
+    unsigned z = (1u << ROW_TILES) - 1u;
+    for (int dt = 0; dt < 5; ++dt) {
+        int f = p + dt - pad;
+        f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+        z &= fz[b * T + f];
+    }
+    skip[nf] = z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+}
 
+// workspace words: 32 (zconst: 64 halves) + nclip*T (frame masks) + nclip*(T+2*pad-4) (position skip masks)
+size_t conv1_zmask_elems(int nclip, int T) { return (size_t)32 + (size_t)nclip * T + (size_t)nclip * (T + 20); }
+
+// Zero-band scan + per-position skip masks + the zero-patch constant into `zscratch` (conv1_zmask_elems words).
+hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale, unsigned* zscratch, hipStream_t s) {
+    if (nclip * T <= 0) return hipSuccess;
+    const int P = T + 2 * pad - 4;
+    unsigned* fz = zscratch + 32;
+    unsigned* sk = fz + (size_t)nclip * T;
+    f16* zc = reinterpret_cast<f16*>(zscratch);
+    hipLaunchKernelGGL(conv1_zero_scan_kernel, dim3((unsigned)(nclip * T)), dim3(256), 0, s, src, fz, Wd, scale * 16777216.0f, zc);
+    hipLaunchKernelGGL(conv1_skip_mask_kernel, dim3((unsigned)((nclip * P + 255) / 256)), dim3(256), 0, s, fz, nclip, T, pad, P, sk);
+    return hipGetLastError();
+}
+
+// zscratch: filled by launch_conv1_scan (nullptr: no tile is skipped outright).  The 4 pooled columns that straddle two strips
+// are closed afterwards by launch_conv1_edge_fix.
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, unsigned* zscratch, const EngineOpts& o, hipStream_t s) {
+                               f16* out_pooled, f16* edge, const unsigned* zscratch, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[64] = {};
     if (o.device < 0 || o.device >= 64) return hipErrorInvalidDevice;
     const int num_cu = o.num_cu;
     if (!attr_set[o.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_direct_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set[o.device] = true;
     }
     Conv1Args a;
     a.src = src; a.nclip = nclip; a.T = T; a.pad = pad; a.P = T + 2 * pad - 4;
+    a.dump = edge + (size_t)nclip * (T + 2 * pad - 4) * PH * 4 * 64;
     a.Wd = Wd; a.scale = scale * 16777216.0f; a.out = out_pooled; a.edge = edge;      // 2^24: the loaders feed n * 2^-24 (fp16 subnormals)
     if ((long)nclip * a.P >= (1L << 24)) return hipErrorInvalidValue;     // decode() splits positions with a float reciprocal
     a.nstrips = nclip * a.P * COL_TILES;
@@ -599,12 +701,10 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.zskip = o.conv1_zero_skip ? 1 : 0;
     a.zmask = nullptr;
     a.zconst = nullptr;
-    if (a.zskip && zscratch && nclip * T > 0) {
-        unsigned* zm = zscratch + 32;
-        f16* zc = reinterpret_cast<f16*>(zscratch);
-        hipLaunchKernelGGL(conv1_zero_scan_kernel, dim3((unsigned)(nclip * T)), dim3(256), 0, s, src, zm, Wd, a.scale, zc);
-        a.zmask = zm;
-        a.zconst = zc;
+    if (num_cu > MAX_WGS) return hipErrorInvalidValue;
+    if (a.zskip && zscratch && nclip * T > 0 && (a.nstrips + num_cu - 1) / num_cu + 8 <= MAX_WG_STRIPS) {
+        a.zmask = zscratch + 32 + (size_t)nclip * T;
+        a.zconst = reinterpret_cast<const f16*>(zscratch);
     }
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
@@ -616,7 +716,8 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     }
     if (a.nstrips <= 0) return hipSuccess;
     const unsigned grid = (unsigned)(a.nstrips < num_cu ? a.nstrips : num_cu);
-    hipLaunchKernelGGL(conv1_direct_kernel, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    if (a.dbg || a.tl) hipLaunchKernelGGL(conv1_direct_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(conv1_direct_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, s, a);
     if (tl) {
         (void)hipStreamSynchronize(s);
         // MFMA wave 0: per tile [arrive, pass]; loader wave 4: per tile [arrive, pass, loads issued, pooled]
@@ -630,11 +731,14 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
         }
         if (n) std::fprintf(stderr, "[conv1 timeline] loader wave: %d tiles, barrier wait %.2f us, convert+fill %.2f us, issue loads %.2f us, pool %.2f us per tile\n", n, w2 / n, is / n, po / n, cv / n);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const long n = (long)nclip * a.P * PH * 4 * 8;
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long positions, hipStream_t s) {
+    const long n = positions * PH * 4 * 8;
+    if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(conv1_edge_fix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_pooled, edge, n);
     return hipGetLastError();
 }
 
-size_t conv1_edge_elems(long positions) { return (size_t)positions * PH * 4 * 64; }
+size_t conv1_edge_elems(long positions) { return (size_t)positions * PH * 4 * 64 + (size_t)MAX_WGS * DUMP_HALVES_PER_WG; }

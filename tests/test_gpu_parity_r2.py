@@ -185,6 +185,27 @@ def test_conv1_zero_band_skip_is_bit_identical(engine, models):
     assert rel(out.float(), alt.float()) < 3e-4
 
 
+def test_conv1_call_sequence_stress(engine, models):
+    """Back-to-back conv1 launches of changing geometry (clip lengths 6..60, both paddings, zero-skip on and off) without any
+    host synchronisation in between, each checked against the first result for its geometry.  Guards the hand-counted waits of the
+    loader waves (inline-asm frame loads: a VALU-written base register once reached the load 5 wait states too early and
+    faulted only in sequences like this one) and workgroups that own no strip at all (tiny launches)."""
+    seq = [(6, 12, 1), (6, 12, 0), (6, 4, 1), (6, 4, 0), (9, 4, 1), (9, 4, 0), (30, 4, 1), (7, 4, 1), (60, 4, 1), (25, 0, 1)] * 3
+    frames = {T: torch.from_numpy(synth.synth_frames(9001 + T, 1, T)).cuda() for T in {q[0] for q in seq}}
+    first = {}
+    try:
+        for T, pad, zs in seq:
+            engine.set_option("conv1_zero_skip", zs)
+            out = engine.debug_conv1_pool(frames[T], pad)
+            key = (T, pad)
+            if key in first:
+                assert torch.equal(out, first[key]), (T, pad, zs)
+            else:
+                first[key] = out.clone()
+    finally:
+        engine.set_option("conv1_zero_skip", 1)
+
+
 # ------------------------------------------------------------------ (d) bias correction calibrated on the wrong data
 def test_bias_correction_with_mismatched_calibration(option_case):
     """JG_PREC_FP16_BC folds (w - fp16(w)).E[x] into the bias with E[x] from calibration clips.  Calibrate on data that
