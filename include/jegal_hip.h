@@ -50,7 +50,7 @@ int jg_set_precision(jg_handle* h, int mode);
 int jg_set_chunk(jg_handle* h, int clips_per_chunk);
 /* tuning / A-B switches, per handle (all default to the fast setting; results stay within the parity tolerance either way):
  *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel
- *   "conv1_zero_skip" 1: all-zero input tiles (the face-mask rows) run only the bias slots (bit-identical)
+ *   "conv1_zero_skip" 1: all-zero input bands (the face-mask rows) are skipped / run only the bias slots (bit-identical)
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
  *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64

@@ -20,6 +20,6 @@ n = 5
 for _ in range(n):
     eng.debug_conv1_pool(frames, 4)
 p = eng.profile_get()
-print("%s DBG=%s PRIO=%s: conv1 kernel %.3f ms, scan+edge %.3f ms per %d clips  (x4 = %.2f ms per 32)" % (
-    "dense" if dense else "masked", os.environ.get("JG_CONV1_DBG", "0"), os.environ.get("JG_CONV1_PRIO", "0"),
+print("%s DBG=%s : conv1 kernel %.3f ms, scan+edge %.3f ms per %d clips  (x4 = %.2f ms per 32)" % (
+    "dense" if dense else "masked", os.environ.get("JG_CONV1_DBG", "0"), 
     p["conv1"][0] / n, p["conv1_aux"][0] / n, B, 4 * p["conv1"][0] / n))
