@@ -381,7 +381,9 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 const int rt = __builtin_ctz(m);
                 const int ph = 2 * rt - 1 + prow;
                 if (ph >= 0 && pw < PW)
-                    __builtin_nontemporal_store(cz, reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8));
+                    // plain store: as nontemporal stores these seven back-to-back 64-byte half-line writes per thread cost
+                    // 1.45x the bytes at the memory side (WRITE_SIZE 3.25 vs 2.22 GB per 32 clips)
+                    *reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8) = cz;
                 if (ph >= 0 && j > 0 && ppw == 0)
                     *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = cz;
             }
