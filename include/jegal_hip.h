@@ -51,6 +51,8 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
 /* tuning / A-B switches, per handle (all default to the fast setting; results stay within the parity tolerance either way):
  *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel
  *   "conv1_zero_skip" 1: all-zero input bands (the face-mask rows) are skipped / run only the bias slots (bit-identical)
+ *   "conv2_row_skip"  1: conv2 does not compute the leading output rows that the zero-band scan proves to be copies of one
+ *                     row (their whole 5x5 window lies in conv1's constant region); they are copied instead (bit-identical)
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
  *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
@@ -81,6 +83,9 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, 
 /* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,
  * pad = temporal edge padding (12 for clips, 0 for a raw 25-frame window) -> out (B*(T+2*pad-4),43,78,64) fp16 NHWC. */
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16);
+/* Check point for "conv2_row_skip": how many leading conv2 output rows per image the last conv stack left to the copy kernel
+ * (0: none, or the option is off).  Synchronises the stream. */
+int jg_debug_conv2_rowskip(jg_handle* h, int* rows);
 /* Tuning aid: ms per launch of the production GEMM for a shape (mode bit0 hi+lo weights, bit1 fp32 residual in/out, bit2 ReLU). */
 int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms);
 /* Drop-in for GestSync.forward_vid(x, return_feats) (gestsync.py:148-162): x (N,3,25,270,480) fp32

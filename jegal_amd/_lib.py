@@ -34,6 +34,7 @@ _SIGS = {
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
     "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
     "jg_debug_gemm": [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
+    "jg_debug_conv2_rowskip": [_P, ctypes.POINTER(ctypes.c_int)],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
@@ -226,6 +227,12 @@ class Engine:
         ms = ctypes.c_double()
         self._ck(self.lib.jg_debug_gemm(self.h, M, N, K, mode, iters, ctypes.byref(ms)))
         return ms.value
+
+    def debug_conv2_rowskip(self):
+        """Leading conv2 output rows per image that the last conv stack copied instead of computing ("conv2_row_skip")."""
+        rows = ctypes.c_int()
+        self._ck(self.lib.jg_debug_conv2_rowskip(self.h, ctypes.byref(rows)))
+        return rows.value
 
     def debug_conv1_pool(self, frames_u8, pad):
         """conv1+BN+ReLU+maxpool only: (B,T,270,480,3) u8 -> (B*(T+2*pad-4),43,78,64) fp16 NHWC."""

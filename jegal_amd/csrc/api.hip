@@ -77,6 +77,8 @@ struct jg_handle {
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
+    bool conv2_row_skip = true;    // conv2 leaves out the leading output rows that the zero-band scan proves to be copies of one row
+    const int* last_rowskip = nullptr;   // device word the last conv stack's conv2 read its row skip from (jg_debug_conv2_rowskip)
     std::map<std::string, HostTensor> host;
     std::vector<void*> wallocs_gs, wallocs_jg;   // device weights of the GestSync / JEGAL model (freed on re-finalize)
     std::vector<void*>* wallocs = &wallocs_gs;   // list the model being finalized allocates into
@@ -460,6 +462,7 @@ ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int P
     g.OW = (W + 2 * PW - KW) / SW + 1;
     g.cshift = 0;
     while ((1 << g.cshift) < C) ++g.cshift;
+    g.rowskip = nullptr;
     return g;
 }
 
@@ -483,7 +486,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     const long NF = (long)nclip * P;
     f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
-    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);      // 20 x 37   (taps in parity-class order, as packed)
+    ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);            // 20 x 37   (taps in parity-class order, as packed)
     const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);     // 10 x 19
     const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);     // 10 x 10
     const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);     // 10 x 10
@@ -504,6 +507,10 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
         RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr));
+        // the zero-band scan also knows how many leading rows of conv2's output are copies of one row (conv1.hip,
+        // conv1_skip_mask_kernel): conv2 computes the others, launch_conv_rows_replicate fills them in
+        if (h->opts.conv1_zero_skip && h->conv2_row_skip && NF * 20 * 37 < (1L << 24))
+            g2.rowskip = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -515,6 +522,8 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     }
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
+    if (g2.rowskip) RET(timed(h, JG_ST_CONV, [&] { return launch_conv_rows_replicate(o2, (int)NF, g2.OH, g2.OW, 128, g2.rowskip, h->stream); }));
+    h->last_rowskip = g2.rowskip;
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
     e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
@@ -922,6 +931,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_tall_tile")) { o.gemm_tall_tile = value != 0; return JG_OK; }
@@ -932,6 +942,16 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "gemm_stagger")) { o.gemm_stagger = value; return JG_OK; }
     if (!std::strcmp(name, "gemm_timeline")) { DeviceGuard dg(h->device); engine_opts_set_timeline(o, value != 0); return JG_OK; }
     JG_FAIL(h, JG_ERR_ARG, "unknown option '%s'", name);
+}
+
+int jg_debug_conv2_rowskip(jg_handle* h, int* rows) {
+    ENTER(h);
+    if (!rows) JG_FAIL(h, JG_ERR_ARG, "rows is NULL");
+    *rows = 0;
+    if (!h->last_rowskip) return JG_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(rows, h->last_rowskip, sizeof(int), hipMemcpyDeviceToHost));
+    return JG_OK;
 }
 
 int jg_sync(jg_handle* h) {

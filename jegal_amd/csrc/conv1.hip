@@ -607,6 +607,8 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
 //   3. band flags -> 22-bit mask.
 // Block 0 also computes the constant every all-zero patch produces: relu(bias) as the MFMA path rounds it (conv1 bias = the
 // hi+lo pair on the pad lane of slots 0 and 1, times 2^-24; both products and their sum are exact in fp32).
+__device__ __forceinline__ int* zmask_hdr(f16* zconst) { return reinterpret_cast<int*>(zconst); }   // zconst = word 0 of the header
+
 __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __restrict__ src, unsigned* __restrict__ zmask,
                                                               const f16* __restrict__ Wd, float scale, f16* __restrict__ zconst) {
     __shared__ int rowz[IH + 2];
@@ -642,36 +644,58 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
         const float acc = hi * 5.9604644775390625e-8f + lo * 5.9604644775390625e-8f;          // 2^-24: the pad lane's "1.0"
         zconst[tid] = (f16)fmaxf(acc * scale, 0.f);
     }
+    // reset the launch-wide minimum that conv1_skip_mask_kernel (next on the stream) reduces into
+    if (blockIdx.x == 0 && tid == 64) zmask_hdr(zconst)[CONV1_ROWSKIP_WORD] = 0x7fffffff;
 }
 
 // position nf = (clip b, padded-clip position p) reads frames clamp(p + dt - pad), dt = 0..4: a tile is all-zero for the position
 // when its band is zero in all five; it is SKIPPED when the tiles above and below are all-zero too (or do not exist), so that
 // both of its pooled rows and its carry are the constant whatever the neighbours hold.
-__global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip) {
+// It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output are one constant row:
+// with row tiles 0..L-1 skipped (so band L is zero too) the pooled rows 0..2L hold relu(bias) in every column, and conv2
+// (5x5, stride 2, no padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-2 are identical pixel for pixel.  The
+// conv2 GEMM then computes rows >= L-2 only and row L-2 is copied upwards (launch_conv_rows_replicate); *rowskip = min (L-2).
+__global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip,
+                                       int* __restrict__ rowskip) {
     const int nf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nf >= nclip * P) return;
-    const int b = nf / P, p = nf - b * P;
-    unsigned z = (1u << ROW_TILES) - 1u;
-    for (int dt = 0; dt < 5; ++dt) {
-        int f = p + dt - pad;
-        f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
-        z &= fz[b * T + f];
+    int rs = 0x7fffffff;
+    if (nf < nclip * P) {
+        const int b = nf / P, p = nf - b * P;
+        unsigned z = (1u << ROW_TILES) - 1u;
+        for (int dt = 0; dt < 5; ++dt) {
+            int f = p + dt - pad;
+            f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+            z &= fz[b * T + f];
+        }
+        const unsigned sk = z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+        skip[nf] = sk;
+        const int L = __builtin_ctz(~sk);                // sk has 22 bits: L <= 22
+        constexpr int C2_OH = (PH - 5) / 2 + 1;          // conv2 output rows (20)
+        rs = L >= 2 ? L - 2 : 0;
+        rs = rs < C2_OH ? rs : C2_OH - 1;                // an all-black position: every row is a copy of the last one
     }
-    skip[nf] = z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(rs, d, 64);
+        rs = o < rs ? o : rs;
+    }
+    if ((threadIdx.x & 63) == 0 && rs != 0x7fffffff) atomicMin(rowskip, rs);
 }
 
-// workspace words: 32 (zconst: 64 halves) + nclip*T (frame masks) + nclip*(T+2*pad-4) (position skip masks)
-size_t conv1_zmask_elems(int nclip, int T) { return (size_t)32 + (size_t)nclip * T + (size_t)nclip * (T + 20); }
+// workspace words: header of CONV1_ZHDR_WORDS (zconst: 64 halves = 32 words; word CONV1_ROWSKIP_WORD: constant leading rows of
+// conv2's output) + nclip*T (frame masks) + nclip*(T+2*pad-4) (position skip masks)
+size_t conv1_zmask_elems(int nclip, int T) { return (size_t)CONV1_ZHDR_WORDS + (size_t)nclip * T + (size_t)nclip * (T + 20); }
 
 // Zero-band scan + per-position skip masks + the zero-patch constant into `zscratch` (conv1_zmask_elems words).
 hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale, unsigned* zscratch, hipStream_t s) {
     if (nclip * T <= 0) return hipSuccess;
     const int P = T + 2 * pad - 4;
-    unsigned* fz = zscratch + 32;
+    unsigned* fz = zscratch + CONV1_ZHDR_WORDS;
     unsigned* sk = fz + (size_t)nclip * T;
     f16* zc = reinterpret_cast<f16*>(zscratch);
     hipLaunchKernelGGL(conv1_zero_scan_kernel, dim3((unsigned)(nclip * T)), dim3(256), 0, s, src, fz, Wd, scale * 16777216.0f, zc);
-    hipLaunchKernelGGL(conv1_skip_mask_kernel, dim3((unsigned)((nclip * P + 255) / 256)), dim3(256), 0, s, fz, nclip, T, pad, P, sk);
+    hipLaunchKernelGGL(conv1_skip_mask_kernel, dim3((unsigned)((nclip * P + 255) / 256)), dim3(256), 0, s, fz, nclip, T, pad, P, sk,
+                       reinterpret_cast<int*>(zscratch) + CONV1_ROWSKIP_WORD);
     return hipGetLastError();
 }
 
@@ -705,7 +729,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.zconst = nullptr;
     if (num_cu > MAX_WGS) return hipErrorInvalidValue;
     if (a.zskip && zscratch && nclip * T > 0 && (a.nstrips + num_cu - 1) / num_cu + 8 <= MAX_WG_STRIPS) {
-        a.zmask = zscratch + 32 + (size_t)nclip * T;
+        a.zmask = zscratch + CONV1_ZHDR_WORDS + (size_t)nclip * T;
         a.zconst = reinterpret_cast<const f16*>(zscratch);
     }
     static unsigned long long* tl = nullptr;

@@ -223,6 +223,34 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     const int fsw = (frow >> 1) & 7;
     const int lrow = lane >> 3, pc = lane & 7;
 
+    // CONV with ConvGeom::rowskip: the first `rsk` output rows of every image are not computed.  The kernel then runs over the
+    // compacted row index m' (images of (OH - rsk) x OW pixels); Mrows replaces a.M, and row_full() maps m' to the row of the
+    // full output the epilogue writes.  m' < 2^24 (checked by the launcher): the image index comes from a float reciprocal.
+    int Mrows = a.M, rsk = 0, perc = 1;
+    long rsk_rows = 0;
+    float inv_perc = 0.f;
+    if constexpr (CONV) {
+        if (a.g.rowskip) {
+            rsk = __builtin_amdgcn_readfirstlane(*a.g.rowskip);
+            rsk = rsk > 0 && rsk < a.g.OH ? rsk : 0;
+            if (rsk) {
+                const int nimg = a.M / (a.g.OH * a.g.OW);
+                perc = (a.g.OH - rsk) * a.g.OW;
+                Mrows = nimg * perc;
+                inv_perc = 1.0f / (float)perc;
+                rsk_rows = (long)rsk * a.g.OW;
+                total_tiles = ((Mrows + BM - 1) / BM) * n_tiles;
+            }
+        }
+    }
+    auto row_full = [&](int m) -> long {
+        if (!CONV || rsk == 0) return m;
+        int img = (int)((float)m * inv_perc);
+        const int base = img * perc;
+        img += base > m ? -1 : (base + perc <= m ? 1 : 0);
+        return (long)m + (long)(img + 1) * rsk_rows;
+    };
+
     // Persistent: one workgroup per CU walks rounds of G tiles.  Within a round the workgroups of one
     // XCD (b, b+8, ...) take consecutive tile ids, so the N tiles of an activation panel share an L2.
     auto tile_of = [&](int round) -> int {
@@ -263,11 +291,12 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             const int row = (wave * XI + i) * 8 + lrow;
             const int c = pc ^ ((row >> 1) & 7);
             int m = m0 + row;
-            m = m < a.M ? m : a.M - 1;
+            m = m < Mrows ? m : Mrows - 1;
             if (CONV) {
-                const int per = a.g.OH * a.g.OW;
+                const int per = rsk ? perc : a.g.OH * a.g.OW;
                 const int img = m / per, rem = m - img * per;
-                const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+                const int ohc = rem / a.g.OW, ow = rem - ohc * a.g.OW;
+                const int oh = ohc + rsk;
                 const int ih = oh * a.g.SH - a.g.PH, iw = ow * a.g.SW - a.g.PW;
                 xpix[i] = (ih << 16) | (iw & 0xffff);
                 xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
@@ -419,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         __builtin_amdgcn_s_barrier();
         mark();     // 0: tile start (first k-tile landed)
         const int cn0 = n0, cm0 = m0;
-        const bool interior = cm0 + BM <= a.M && cn0 + BN <= a.N;
+        const bool interior = cm0 + BM <= Mrows && cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
         const int mb = cm0 + wm * (16 * MI) + frow;
         // spreading the DMA pieces over the MFMA schedule, measured: -16 % on the 128x512 LN kernel (K = 2048), -5 % on the
@@ -649,7 +678,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
-            f16* orow = a.out16 + (long)(cm0 + wm * (16 * MI) + (lane >> 3)) * a.ldc + cn0 + wn * 64 + (lane & 7) * 8;
+            const int orow_m = cm0 + wm * (16 * MI) + (lane >> 3);
+            f16* ocol = a.out16 + cn0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
 #pragma unroll
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
-                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(orow + (long)(j * 16 + h2 * 8) * a.ldc));
+                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(ocol + row_full(orow_m + j * 16 + h2 * 8) * a.ldc));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -690,7 +720,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                const long mo = (long)(mb + j * 16) * a.ldc + nb;
+                const long mo = row_full(mb + j * 16) * a.ldc + nb;
                 f32x4 rj[4];
                 if (!PREFETCH_RES) {
 #pragma unroll
@@ -727,7 +757,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
                     const int m = cm0 + wm * (16 * MI) + j * 16 + frow;
-                    if (m >= a.M) continue;
+                    if (m >= Mrows) continue;
+                    const long mf = row_full(m);
                     f32x4 v = acc[i][j] * sc + bi;
                     if (a.res) {
                         const int rr = a.res_mod ? (m % a.res_mod) : m;
@@ -736,10 +767,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                     if (a.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
+                    if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mf * a.ldc + n) = v;
                     if (a.out16) {
                         f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                        *reinterpret_cast<f16x4*>(a.out16 + (long)m * a.ldc + n) = h;
+                        *reinterpret_cast<f16x4*>(a.out16 + mf * a.ldc + n) = h;
                     }
                 }
             }

@@ -89,7 +89,7 @@ def test_jegal_text_long_sequences(models, oracle_sd, L):
 
 # ------------------------------------------------------------------ (b) every A/B switch and W2_ALL
 OPTIONS = ["attn_mfma", "fuse_ln", "gemm_glds", "gemm_persistent", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile",
-           "gemm_counted", "conv1_zero_skip", "conv1_direct", "edge_dedup"]
+           "gemm_counted", "conv1_zero_skip", "conv2_row_skip", "conv1_direct", "edge_dedup"]
 
 
 @pytest.fixture(scope="module")
@@ -121,7 +121,7 @@ def test_every_option_stays_within_tolerance(engine, models, option_case, opt):
     e_base, e_alt = rel(base, ref), rel(alt, ref)
     print(f"{opt}=0: rel {e_alt:.3e} (default {e_base:.3e}); |alt - default| rel {rel(alt, base):.3e}")
     assert e_base < TOL and e_alt < TOL
-    if opt in ("conv1_zero_skip", "edge_dedup", "gemm_persistent", "gemm_counted"):
+    if opt in ("conv1_zero_skip", "conv2_row_skip", "edge_dedup", "gemm_persistent", "gemm_counted"):
         assert torch.equal(alt, base), f"{opt} only changes scheduling / skips exact zeros: must be bit-identical"
 
 
@@ -183,6 +183,33 @@ def test_conv1_zero_band_skip_is_bit_identical(engine, models):
     finally:
         engine.set_option("conv1_direct", 1)
     assert rel(out.float(), alt.float()) < 3e-4
+
+
+def test_conv2_row_skip_follows_the_zero_bands(engine, models):
+    """conv2 leaves out the leading output rows whose 5x5 windows lie entirely in conv1's constant region and copies the first
+    computed row over them.  The count comes from the zero-band scan, as the minimum over all positions of the launch:
+    rows 0..109 masked -> bands 0..7 zero -> tiles 0..6 skipped (L = 7) -> 5 rows; it must follow the SMALLEST mask of the
+    batch, be 0 for unmasked input, and never change a bit of the embeddings."""
+    rng = np.random.default_rng(99)
+    T = 30
+    cases = []
+    a = rng.integers(1, 256, (2, T, 270, 480, 3), dtype=np.uint8); a[:, :, :110] = 0; cases.append((a, 5))
+    b = a.copy(); b[1, :, :110] = rng.integers(1, 256, (T, 110, 480, 3), dtype=np.uint8); b[1, :, :64] = 0; cases.append((b, 2))  # bands 0..4 -> L = 4
+    c = a.copy(); c[0, 17, 3, 100, 1] = 9; cases.append((c, 0))              # one byte in one frame of one clip: that position has L = 0
+    d = rng.integers(1, 256, (2, T, 270, 480, 3), dtype=np.uint8); cases.append((d, 0))
+    e = np.zeros((2, T, 270, 480, 3), dtype=np.uint8); cases.append((e, 19))                # black clips: every row is the constant row
+    for clips, want in cases:
+        frames = torch.from_numpy(clips).cuda()
+        out = engine.extract_gesture(frames)
+        got = engine.debug_conv2_rowskip()
+        engine.set_option("conv2_row_skip", 0)
+        try:
+            ref = engine.extract_gesture(frames)
+            assert engine.debug_conv2_rowskip() == 0
+        finally:
+            engine.set_option("conv2_row_skip", 1)
+        assert got == want, (got, want)
+        assert torch.equal(out, ref)
 
 
 def test_conv1_call_sequence_stress(engine, models):
