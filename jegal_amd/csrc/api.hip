@@ -471,11 +471,12 @@ constexpr int FH = 270, FW = 480;
 
 // conv1 + max-pool straight from u8 frames: zero-band scan (stage "conv1_aux"), the fused kernel (stage "conv1": the
 // path's dominant kernel, timed alone), strip-seam fix-up (stage "conv1_aux")
-int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pad, f16* pooled, f16* edge, unsigned* zscr) {
+// fill_all = false: the caller's conv2 honours the row skip the scan leaves in zscr, so the pooled rows it never reads stay unwritten
+int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pad, f16* pooled, f16* edge, unsigned* zscr, bool fill_all) {
     const bool scan = h->opts.conv1_zero_skip;
     if (scan) RET(timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv1_scan(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, zscr, h->stream); }));
     RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, pooled, edge,
-                                                               scan ? zscr : nullptr, h->opts, h->stream); }));
+                                                               scan ? zscr : nullptr, fill_all, h->opts, h->stream); }));
     return timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv1_edge_fix(pooled, edge, (long)nclip * (T + 2 * pad - 4), h->stream); });
 }
 
@@ -506,10 +507,11 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
-        RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr));
+        const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && NF * 20 * 37 < (1L << 24);
+        RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr, !rowskip));
         // the zero-band scan also knows how many leading rows of conv2's output are copies of one row (conv1.hip,
         // conv1_skip_mask_kernel): conv2 computes the others, launch_conv_rows_replicate fills them in
-        if (h->opts.conv1_zero_skip && h->conv2_row_skip && NF * 20 * 37 < (1L << 24))
+        if (rowskip)
             g2.rowskip = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
@@ -1015,7 +1017,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(B, T), &zscr));
-        return conv1_from_frames(h, static_cast<const uint8_t*>(frames_u8), B, T, pad, static_cast<f16*>(out_f16), edge, zscr);
+        return conv1_from_frames(h, static_cast<const uint8_t*>(frames_u8), B, T, pad, static_cast<f16*>(out_f16), edge, zscr, true);
     }
     f16 *o1, *S;
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));

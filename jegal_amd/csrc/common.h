@@ -137,7 +137,7 @@ hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st,
 // launch_conv1_direct (zscratch == nullptr: nothing is skipped), launch_conv1_edge_fix (pooled columns that straddle two strips)
 hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale, unsigned* zscratch, hipStream_t s);
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, const unsigned* zscratch, const EngineOpts& o, hipStream_t s);
+                               f16* out_pooled, f16* edge, const unsigned* zscratch, bool fill_all, const EngineOpts& o, hipStream_t s);
 hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long positions, hipStream_t s);
 size_t conv1_zmask_elems(int nclip, int T);
 size_t conv1_edge_elems(long positions);

@@ -49,6 +49,8 @@ struct Conv1Args {
     const unsigned* zmask;    // [nclip*P] per POSITION: bit rt = tile rt of the position's 5 strips is skipped outright
                               // (conv1_zero_scan_kernel + conv1_skip_mask_kernel); nullptr: no tile is skipped
     const f16* zconst;        // [64] relu(bias) per channel as fp16: the value of every conv1 output whose patch is all zero
+    const int* fill_from;     // nullptr, or the device word conv2 reads its row skip r from (common.h: ConvGeom::rowskip): conv2 then
+                              // reads pooled rows >= 2r only, and the constant fill of the skipped tiles leaves the rows above unwritten
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
                           // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
 };
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // walks would put an s_waitcnt vmcnt(0) -- hipcc cannot count across the walks' loops -- behind every batch of frame loads.
     const unsigned* skip_tab = reinterpret_cast<const unsigned*>(smem + OFF_SKIP);
     const bool use_skip = a.zmask != nullptr;
+    const int fill_lo = a.fill_from ? 2 * __builtin_amdgcn_readfirstlane(*a.fill_from) : 0;     // first pooled row the fill must write
     auto strip_skip = [&](int k) -> unsigned {
         return use_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip_tab[k]) : 0u;
     };
@@ -380,11 +383,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             for (unsigned m = skip; m; m &= m - 1) {
                 const int rt = __builtin_ctz(m);
                 const int ph = 2 * rt - 1 + prow;
-                if (ph >= 0 && pw < PW)
+                if (ph >= fill_lo && pw < PW)
                     // plain store: as nontemporal stores these seven back-to-back 64-byte half-line writes per thread cost
                     // 1.45x the bytes at the memory side (WRITE_SIZE 3.25 vs 2.22 GB per 32 clips)
                     *reinterpret_cast<f16x8*>(a.out + (((long)nf * PH + ph) * PW + pw) * 64 + pcg * 8) = cz;
-                if (ph >= 0 && j > 0 && ppw == 0)
+                if (ph >= fill_lo && j > 0 && ppw == 0)
                     *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = cz;
             }
         };
@@ -702,7 +705,7 @@ hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, cons
 // zscratch: filled by launch_conv1_scan (nullptr: no tile is skipped outright).  The 4 pooled columns that straddle two strips
 // are closed afterwards by launch_conv1_edge_fix.
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
-                               f16* out_pooled, f16* edge, const unsigned* zscratch, const EngineOpts& o, hipStream_t s) {
+                               f16* out_pooled, f16* edge, const unsigned* zscratch, bool fill_all, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[64] = {};
     if (o.device < 0 || o.device >= 64) return hipErrorInvalidDevice;
     const int num_cu = o.num_cu;
@@ -727,10 +730,13 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.zskip = o.conv1_zero_skip ? 1 : 0;
     a.zmask = nullptr;
     a.zconst = nullptr;
+    a.fill_from = nullptr;
     if (num_cu > MAX_WGS) return hipErrorInvalidValue;
     if (a.zskip && zscratch && nclip * T > 0 && (a.nstrips + num_cu - 1) / num_cu + 8 <= MAX_WG_STRIPS) {
         a.zmask = zscratch + CONV1_ZHDR_WORDS + (size_t)nclip * T;
         a.zconst = reinterpret_cast<const f16*>(zscratch);
+        static const bool env_fill_all = getenv("JG_CONV1_FILL_ALL") != nullptr;      // A/B aid
+        if (!fill_all && !env_fill_all) a.fill_from = reinterpret_cast<const int*>(zscratch) + CONV1_ROWSKIP_WORD;
     }
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
