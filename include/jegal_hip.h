@@ -53,6 +53,8 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "conv1_zero_skip" 1: all-zero input bands (the face-mask rows) are skipped / run only the bias slots (bit-identical)
  *   "conv2_row_skip"  1: conv2 does not compute the leading output rows that the zero-band scan proves to be copies of one
  *                     row (their whole 5x5 window lies in conv1's constant region); they are copied instead (bit-identical)
+ *   "qkv0_linear"     1: the first transformer layer's qkv projection runs over the T+4 distinct conv positions and the 21
+ *                     positional rows (linearity of W(conv + pe) + b); the attention kernel gathers and sums the rows
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
  *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64

@@ -77,6 +77,9 @@ struct jg_handle {
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
+    f16* gs_qpe = nullptr;         // [21][1536]: layer-0 W_qkv pe[j] + b (Qkv0); recomputed when weights or bias corrections change
+    bool gs_qpe_valid = false;
+    bool qkv0_linear = true;       // layer-0 qkv projection over the distinct conv positions + gather in the attention kernel
     bool conv2_row_skip = true;    // conv2 leaves out the leading output rows that the zero-band scan proves to be copies of one row
     const int* last_rowskip = nullptr;   // device word the last conv stack's conv2 read its row skip from (jg_debug_conv2_rowskip)
     std::map<std::string, HostTensor> host;
@@ -419,6 +422,7 @@ struct Epi {
     const signed char* res8 = nullptr;
     signed char* out8 = nullptr;
     int a_tiled = 0;
+    int no_bias = 0;              // the layer's bias is applied elsewhere (layer-0 qkv by linearity: it rides in the projected PE rows)
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -428,7 +432,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     if (g) a.g = *g;
     a.Wh = L.wh; a.Wl = (h->calib && L.bc) ? L.wl_calib : L.wl; a.ldw = L.K;
     a.M = M; a.N = L.N; a.K = L.K;
-    a.scale = e.scale; a.bias = L.bias;
+    a.scale = e.scale; a.bias = e.no_bias ? nullptr : L.bias;
     a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
     a.out32 = e.out32; a.out16 = e.out16; a.ldc = e.ldc ? e.ldc : L.N;
     a.relu = e.relu;
@@ -481,8 +485,9 @@ int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pa
 }
 
 // conv stack over `nclip` temporal volumes -> conv_out (nclip*P, 512) fp32, P = T + 2*pad - 4
+// conv16 (optional): fp16 copy of conv_out, the A operand of the per-position qkv projection (gs_transformer, Qkv0)
 int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, long sh, long sw, long sc,
-                  int nclip, int T, int pad, float* conv_out) {
+                  int nclip, int T, int pad, float* conv_out, f16* conv16 = nullptr) {
     const int P = T + 2 * pad - 4;
     const long NF = (long)nclip * P;
     f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
@@ -530,7 +535,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
     e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
     RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream); }));
-    e.out16 = nullptr; e.out32 = conv_out;
+    e.out16 = conv16; e.out32 = conv_out;
     RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
     return JG_OK;
 }
@@ -549,7 +554,16 @@ inline size_t pad128(size_t rows) { return (rows + 127) / 128 * 128; }
 
 // x32/x16 hold pad128(M) rows.  With `tiled` (gs_fused_plan) the token stream is the tiled fp16 plane x16 plus the 8-bit
 // correction plane stored in x32's memory (launch_window_gather(..., tiled = 1)); otherwise fp32 rows + fp16 rows.
-int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled) {
+// Layer 0's qkv projection by linearity (clip path): token j of window (clip c, frame i) is conv[c][clamp(i+j-shift)] + pe[j],
+// so W x + b = W conv[c][p] + (W pe[j] + b).  The projection then runs over the nclip*P distinct conv positions (154 per clip
+// instead of 150 * 21 tokens) plus the 21 positional rows, and the attention kernel gathers and sums the operand rows
+// (attention.hip, attn_mfma_s32_kernel<true>): no 310 MB qkv tensor for layer 0.
+struct Qkv0 {
+    const f16* conv16;    // [nclip*P][512]
+    int nclip, P, Twin, shift;
+};
+
+int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled, const Qkv0* q0 = nullptr) {
     const int M = nseq * S;
     f16 *qkv, *att, *hid;
     RET(wsalloc(h, (size_t)M * 1536, &qkv));
@@ -558,10 +572,27 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
     signed char* d8 = reinterpret_cast<signed char*>(x32);
     for (int l = 0; l < 6; ++l) {
         const EncLayer& L = h->gs_layers[l];
-        Epi e;
-        e.out16 = qkv; e.a_tiled = tiled;
-        RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
+        if (l == 0 && q0) {
+            f16* qpos;
+            RET(wsalloc(h, (size_t)q0->nclip * q0->P * 1536, &qpos));
+            if (!h->gs_qpe) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->gs_qpe), (size_t)32 * 1536 * sizeof(f16)));
+            f16* qpe = h->gs_qpe;
+            Epi e;
+            e.out16 = qpos; e.no_bias = 1;
+            RET(gemm(h, JG_ST_GEMM, q0->conv16, 512, q0->nclip * q0->P, L.qkv, e));
+            if (!h->gs_qpe_valid) {
+                RET(timed(h, JG_ST_GEMM, [&] { return launch_pe_project(h->gs_pe, S, L.qkv.wh, L.qkv.wl, L.qkv.bias, 1536, 512, qpe, h->stream); }));
+                HIPCHK(h, hipStreamSynchronize(h->stream));      // once per weight load: later calls may come on another stream
+                h->gs_qpe_valid = true;
+            }
+            const AttnGather ag = {qpe, q0->Twin, q0->P, q0->shift};
+            RET(timed(h, JG_ST_ATTN, [&] { return launch_attention_gather(qpos, ag, nseq, S, 8, att, h->stream); }));
+        } else {
+            Epi e;
+            e.out16 = qkv; e.a_tiled = tiled;
+            RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
+            RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
+        }
         // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue (row-wide
         // 128x512 tiles, tiled fp16 + 8-bit token stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
         auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
@@ -600,14 +631,18 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         float* conv;
         RET(wsalloc(h, (size_t)nb * P * 512, &conv));
         const char* src = reinterpret_cast<const char*>(frames) + (size_t)b0 * sb * esz;
-        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
         const int nseq = nb * T, M = nseq * S;
-        float* x32; f16 *x16, *hid, *mean16;
+        float* x32; f16 *x16, *hid, *mean16, *conv16 = nullptr;
         const bool tiled = gs_fused_plan(h, M);
+        // layer-0 qkv from the distinct conv positions: worth it when the windows overlap (T > 1) and the MFMA attention runs
+        const bool lin0 = tiled && h->qkv0_linear && h->opts.attn_mfma && T > 1;
+        if (lin0) RET(wsalloc(h, (size_t)nb * P * 512, &conv16));
+        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv, conv16));
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
         RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
-        RET(gs_transformer(h, x32, x16, nseq, S, tiled));
+        const Qkv0 q0 = {conv16, nb, P, T, 12 - PAD};
+        RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
         Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
@@ -734,6 +769,7 @@ int apply_bias_corrections(jg_handle* h) {
         HIPCHK(h, hipMemcpy(L->bias, nb.data(), sizeof(float) * L->N, hipMemcpyHostToDevice));
         L->mu_rows = 0;
     }
+    h->gs_qpe_valid = false;          // the projected positional rows carry layer 0's qkv bias
     return JG_OK;
 }
 
@@ -896,6 +932,7 @@ int jg_destroy(jg_handle* h) {
         for (void* p : h->wallocs_gs) hipFree(p);
         for (void* p : h->wallocs_jg) hipFree(p);
         if (h->feats) hipFree(h->feats);
+        if (h->gs_qpe) hipFree(h->gs_qpe);
         h->ws.release();
         engine_opts_release(h->opts);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -934,6 +971,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "qkv0_linear")) { h->qkv0_linear = value != 0; return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_tall_tile")) { o.gemm_tall_tile = value != 0; return JG_OK; }
@@ -983,6 +1021,7 @@ int jg_load_tensor(jg_handle* h, const char* name, const void* data, const int64
 
 int jg_finalize_weights(jg_handle* h, int which) {
     ENTER(h);
+    h->gs_qpe_valid = false;
     if (which & 1) RET(finalize_gestsync(h));
     if (which & 2) RET(finalize_jegal(h));
     // the fp32 host copies of the checkpoint (incl. the unused audio/LSTM tensors of gestsync.py:23-32) are no longer

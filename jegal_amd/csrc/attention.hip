@@ -171,43 +171,96 @@ __global__ __launch_bounds__(256) void attn_kernel(const f16* __restrict__ qkv, 
 //                 keep fp32 accuracy, as in the VALU kernel, and the matrix pipe has nothing else to do.
 //   The output tile is transposed back through LDS so the stores are whole 128-B rows.
 // Rows >= S are clamped on load (finite values), masked to -inf as keys and never stored as queries.
-__global__ __launch_bounds__(256) void attn_mfma_s32_kernel(const f16* __restrict__ qkv, int npairs, int S, int H, f16* __restrict__ out) {
+// GATHER (layer 0 of the GestSync transformer, AttnGather in common.h): token j of window (clip c, frame i) is
+//   x = conv[c][clamp(i + j - shift)] + pe[j],  so its projection is  W x + b = (W conv[c][p]) + (W pe[j] + b):
+// `qkv` then holds ONE projected row per distinct conv position ([clip][P][3D], 154 rows per clip instead of 3150) and
+// `g.pe_qkv` the 21 projected positional rows incl. the bias; the operand rows are gathered and summed here.  The windows
+// of a clip re-read the same 154 rows, so the blocks are dealt to the XCDs in contiguous ranges (whole clips per L2).
+// OR = rows of the K / Q / output image in LDS, >= S: 24 for the GestSync windows (S = 21) -- 8064 B per wave, five
+// workgroups (20 waves) per CU, which is also what the 96 VGPRs allow; the kernel is bound by its per-wave latency chain
+// (load -> LDS -> MFMA -> softmax -> LDS -> MFMA -> LDS -> store), so the number of waves in flight is what counts.
+template <bool GATHER, int OR>
+__global__ __launch_bounds__(256, 5) void attn_mfma_s32_kernel(const f16* __restrict__ qkv, int npairs, int S, int H, f16* __restrict__ out, AttnGather g) {
     constexpr int DK = 64, VT_PITCH = 72, O_PITCH = 144;
-    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * VT_PITCH + 32 * O_PITCH)];
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * VT_PITCH + OR * O_PITCH)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x * 4 + wave;
+    int wg = blockIdx.x;
+    if (GATHER) {
+        const int per = ((int)gridDim.x + 7) >> 3;
+        wg = (wg & 7) * per + (wg >> 3);
+    }
+    const int pair = wg * 4 + wave;
     if (pair >= npairs) return;
-    char* sVt = smem + wave * (64 * VT_PITCH + 32 * O_PITCH);
+    char* sVt = smem + wave * (64 * VT_PITCH + OR * O_PITCH);
+    const int r31o = (lane & 31) < OR ? (lane & 31) : OR - 1;       // rows >= OR only exist as clamped copies (masked keys, unused queries)
     char* sO = sVt + 64 * VT_PITCH;
     const int b = pair / H, head = pair - b * H;
     const int D = H * DK;
     const long ld = 3L * D;
-    const f16* base = qkv + (long)b * S * ld + head * DK;
+    const f16* base = qkv + (GATHER ? 0L : (long)b * S * ld) + head * DK;
     const int r31 = lane & 31, hh = lane >> 5;
     const int rowc = r31 < S ? r31 : S - 1;
+    // GATHER: source row of token j
+    int gc = 0, gi = 0;
+    if (GATHER) { gc = b / g.Twin; gi = b - gc * g.Twin - g.shift; }
+    auto src_row = [&](int j) -> long {
+        if (!GATHER) return j;
+        int p = gi + j;
+        p = p < 0 ? 0 : (p > g.P - 1 ? g.P - 1 : p);
+        return (long)gc * g.P + p;
+    };
 
-    // ---- operand loads (issued together; V goes through LDS)
-    f16x8 kA[4], qB[4];
-    const f16* qrow = base + (long)rowc * ld + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qB[s] = *reinterpret_cast<const f16x8*>(qrow + 16 * s);
-        kA[s] = *reinterpret_cast<const f16x8*>(qrow + D + 16 * s);
-    }
-    f16x8 vv[4];
+    // ---- operand loads.  Every row's 128-byte q, k and v slices are read by 8 lanes x 16 B (8 cache lines per load
+    // instruction; with lane = row and 16 B per lane a load touches 32 lines and the kernel ends up bound by the CU's
+    // address/tag path, not by HBM), and all three operands go through LDS: K, then Q, row-major in the buffer that later
+    // holds the output tile (a wave's LDS operations execute in order), V transposed.
+    f16x8 qq[4], kk[4], vv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = lane + 64 * r, row = c >> 3, part = c & 7;
         const int rc = row < S ? row : S - 1;
-        vv[r] = *reinterpret_cast<const f16x8*>(base + (long)rc * ld + 2 * D + part * 8);
+        const f16* p = base + src_row(rc) * ld + part * 8;
+        qq[r] = *reinterpret_cast<const f16x8*>(p);
+        kk[r] = *reinterpret_cast<const f16x8*>(p + D);
+        vv[r] = *reinterpret_cast<const f16x8*>(p + 2 * D);
     }
+    if (GATHER) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+            const int rc = row < S ? row : S - 1;
+            const f16* p = g.pe_qkv + (long)rc * ld + head * DK + part * 8;
+            qq[r] += *reinterpret_cast<const f16x8*>(p);
+            kk[r] += *reinterpret_cast<const f16x8*>(p + D);
+            vv[r] += *reinterpret_cast<const f16x8*>(p + 2 * D);
+        }
+    }
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    f16x8 kA[4], qB[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+        if (OR == 32 || row < OR) *reinterpret_cast<f16x8*>(sO + row * O_PITCH + part * 16) = kk[r];
 #pragma unroll
         for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(sVt + (part * 8 + e) * VT_PITCH + row * 2) = vv[r][e];
     }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kA[s] = *reinterpret_cast<const f16x8*>(sO + r31o * O_PITCH + (8 * hh + 16 * s) * 2);
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = lane + 64 * r, row = c >> 3, part = c & 7;
+        if (OR == 32 || row < OR) *reinterpret_cast<f16x8*>(sO + row * O_PITCH + part * 16) = qq[r];
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qB[s] = *reinterpret_cast<const f16x8*>(sO + r31o * O_PITCH + (8 * hh + 16 * s) * 2);
 
     // ---- S^T = K Q^T
     f32x16 sc;
@@ -269,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_mfma_s32_kernel(const f16* __restric
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f16x4 hv = {(f16)o[blk][4 * g], (f16)o[blk][4 * g + 1], (f16)o[blk][4 * g + 2], (f16)o[blk][4 * g + 3]};
-            *reinterpret_cast<f16x4*>(sO + r31 * O_PITCH + (32 * blk + 8 * g + 4 * hh) * 2) = hv;
+            if (OR == 32 || r31 < OR) *reinterpret_cast<f16x4*>(sO + r31 * O_PITCH + (32 * blk + 8 * g + 4 * hh) * 2) = hv;
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -423,11 +476,24 @@ static hipError_t launch_attn_mfma(const f16* qkv, const float* keymask, long np
     return hipGetLastError();
 }
 
+// Layer-0 attention of the GestSync transformer from per-position projections (see attn_mfma_s32_kernel<true>):
+// B = windows (nclip * g.Twin), S <= 32 tokens, dk = 64.
+hipError_t launch_attention_gather(const f16* qkv_pos, const AttnGather& g, int B, int S, int H, f16* out, hipStream_t s) {
+    if (B <= 0 || S <= 0) return hipSuccess;
+    const long npairs = (long)B * H;
+    if (S > 32 || npairs >= (1L << 31) || g.Twin <= 0 || g.P <= 0 || !g.pe_qkv) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((npairs + 3) / 4);
+    if (S <= 24) hipLaunchKernelGGL((attn_mfma_s32_kernel<true, 24>), dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, qkv_pos, (int)npairs, S, H, out, g);
+    else hipLaunchKernelGGL((attn_mfma_s32_kernel<true, 32>), dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, qkv_pos, (int)npairs, S, H, out, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, const EngineOpts& o, hipStream_t s) {
     if (B <= 0 || S <= 0) return hipSuccess;
     const long npairs = (long)B * H;
     if (o.attn_mfma && S <= 32 && dk == 64 && !keymask && npairs < (1L << 31)) {
-        hipLaunchKernelGGL(attn_mfma_s32_kernel, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out);
+        if (S <= 24) hipLaunchKernelGGL((attn_mfma_s32_kernel<false, 24>), dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out, AttnGather{});
+        else hipLaunchKernelGGL((attn_mfma_s32_kernel<false, 32>), dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, qkv, (int)npairs, S, H, out, AttnGather{});
         return hipGetLastError();
     }
     if (o.attn_mfma && S <= 160 && dk == 64 && npairs < (1L << 31)) {      // S <= 32 with a key mask: one query block

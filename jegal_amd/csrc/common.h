@@ -148,6 +148,15 @@ hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P
 hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,
                             int relu, float* out32, f16* out16, hipStream_t s);
 hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, int H, int dk, f16* out, const EngineOpts& o, hipStream_t s);
+// Window structure of the GestSync clip path for attention straight from per-position projections (attention.hip):
+// token j of window (clip c, frame i) comes from conv position clamp(i + j - shift, 0, P - 1) of clip c.
+struct AttnGather {
+    const f16* pe_qkv;    // [S][3D]: W_qkv pe[j] + b
+    int Twin, P, shift;   // windows per clip, conv positions per clip, window_gather's shift
+};
+hipError_t launch_attention_gather(const f16* qkv_pos, const AttnGather& g, int B, int S, int H, f16* out, hipStream_t s);
+// pe_qkv[j][n] = sum_k W[n][k] pe[j][k] + bias[n]  (W = Wh (+ Wl), [N][K] fp16; pe [S][K] fp32): 21 x 1536 outputs
+hipError_t launch_pe_project(const float* pe, int S, const f16* Wh, const f16* Wl, const float* bias, int N, int K, f16* out, hipStream_t s);
 hipError_t launch_group_mean(const f16* in, int groups, int L, int D, f16* out, hipStream_t s);
 hipError_t launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s);
 hipError_t launch_transpose_tokens(const float* in, int N, int L, int D, float* out, hipStream_t s);

@@ -88,6 +88,28 @@ hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int
     return hipGetLastError();
 }
 
+// Projection of the positional rows through a Linear layer (layer-0 qkv by linearity, attention.hip): one wave per output.
+__global__ __launch_bounds__(256) void pe_project_kernel(const float* __restrict__ pe, int S, const f16* __restrict__ Wh, const f16* __restrict__ Wl,
+                                                         const float* __restrict__ bias, int N, int K, f16* __restrict__ out) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= S * N) return;
+    const int j = o / N, n = o - j * N;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float w = (float)Wh[(long)n * K + k];
+        if (Wl) w += (float)Wl[(long)n * K + k];
+        acc += w * pe[(long)j * K + k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) out[o] = (f16)(acc + (bias ? bias[n] : 0.f));
+}
+
+hipError_t launch_pe_project(const float* pe, int S, const f16* Wh, const f16* Wl, const float* bias, int N, int K, f16* out, hipStream_t s) {
+    hipLaunchKernelGGL(pe_project_kernel, dim3((unsigned)((S * N + 3) / 4)), dim3(256), 0, s, pe, S, Wh, Wl, bias, N, K, out);
+    return hipGetLastError();
+}
+
 // Rows 0..*rowskip-1 of every (OH, OW, C) image <- row *rowskip of the same image (ConvGeom::rowskip: the conv kernel left them
 // out because they are copies of that row).  One workgroup per (image, 2 KB slice of the row); *rowskip == 0: nothing to do.
 __global__ __launch_bounds__(128) void conv_rows_replicate_kernel(f16* __restrict__ out, int OH, long row_halves, const int* __restrict__ rowskip) {
