@@ -136,7 +136,7 @@ hipError_t launch_conv_rows_replicate(f16* out, int nimg, int OH, int OW, int C,
 // shift/clamp: with edge padding the first 9 and last 9 padded-clip positions see five copies of the
 // same frame, so the conv stack is only evaluated for the T+4 distinct positions (shift = 8).
 __global__ void window_gather_kernel(const float* __restrict__ conv, const float* __restrict__ pe, int B, int P, int Twin,
-                                     int L, int D, int shift, int tiled, float* __restrict__ x32, f16* __restrict__ x16) {
+                                     int L, int D, int shift, float* __restrict__ x32, f16* __restrict__ x16) {
     const int dv = D / 4;
     const long total = (long)B * Twin * L * dv;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -151,31 +151,69 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
         f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + pp) * D + d4 * 4);
         v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
         const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-        if (tiled) {
-            // token stream of the fused GEMM+LayerNorm kernel: tiled fp16 plane + 8-bit correction plane
-            // (layouts and res_enc in common.h); x32 is the correction plane here
-            const long row = idx / dv;
-            const int col = d4 * 4;
-            const int rr = (int)(row & 127);
-            const long blk = (row >> 7) * 65536 + (col >> 6) * 8192 + (rr >> 4) * 1024;
-            *reinterpret_cast<f16x4*>(x16 + blk + ((col & 63) >> 4) * 256 + (rr & 15) * 16 + (col & 15)) = h;
-            const unsigned dw = (unsigned)(res_enc(v.x, h[0]) & 0xff) | ((unsigned)(res_enc(v.y, h[1]) & 0xff) << 8) |
-                                ((unsigned)(res_enc(v.z, h[2]) & 0xff) << 16) | ((unsigned)(res_enc(v.w, h[3]) & 0xff) << 24);
-            const int ln = ((col & 15) >> 2) * 16 + (rr & 15);
-            *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(x32) + blk + ln * 16 + ((col & 63) >> 4) * 4) = dw;
-        } else {
+        {
             *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
             *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
         }
     }
 }
 
+// Tiled variant (token stream of the fused GEMM+LayerNorm kernel, layouts and res_enc in common.h; x32 is the 8-bit
+// correction plane): one wave per 16-row x 64-column block, lane = (column quad ng, row m15) exactly as in the LN epilogue
+// of gemm_glds_kernel -- a lane holds columns 16q + 4ng .. +3 (q = 0..3) of its row, so every store instruction of the wave
+// covers a contiguous 512 B (fp16 plane, one per q) or 1 KB (correction plane).  (The element-per-thread kernel above wrote
+// 32-byte pieces 512 B apart: 67 us for the 155 MB of a 32-clip chunk.)
+__global__ __launch_bounds__(256) void window_gather_tiled_kernel(const float* __restrict__ conv, const float* __restrict__ pe, int B, int P, int Twin,
+                                                                  int L, int shift, signed char* __restrict__ d8, f16* __restrict__ x16) {
+    const long M = (long)B * Twin * L;
+    const long nblk = ((M + 15) >> 4) * 8;
+    const long blk = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (blk >= nblk) return;
+    const int lane = threadIdx.x & 63, m15 = lane & 15, ng = lane >> 4;
+    const long rb = blk >> 3;                       // 16-row block
+    const int cb = (int)(blk & 7);                  // 64-column block
+    long row = rb * 16 + m15;
+    const bool live = row < M;
+    row = live ? row : M - 1;
+    // 32-bit index math (the launcher checks M < 2^31): 64-bit divisions by run-time values cost ~100 VALU instructions each and
+    // made this store-bound kernel VALU-bound
+    const unsigned r32 = (unsigned)row;
+    const unsigned r2 = r32 / (unsigned)L;
+    const int j = (int)(r32 - r2 * (unsigned)L);
+    const unsigned b = r2 / (unsigned)Twin;
+    const int i = (int)(r2 - b * (unsigned)Twin);
+    int pp = i + j - shift;
+    pp = pp < 0 ? 0 : (pp > P - 1 ? P - 1 : pp);
+    const float* src = conv + ((long)b * P + pp) * 512 + cb * 64 + 4 * ng;
+    const float* pes = pe + (long)j * 512 + cb * 64 + 4 * ng;
+    const long base = (rb >> 3) * 65536 + (long)cb * 8192 + (rb & 7) * 1024;
+    unsigned dq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + 16 * q);
+        v += *reinterpret_cast<const f32x4*>(pes + 16 * q);
+        const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        if (live) __builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(x16 + base + q * 256 + m15 * 16 + 4 * ng));
+        dq[q] = (unsigned)(res_enc(v.x, h[0]) & 0xff) | ((unsigned)(res_enc(v.y, h[1]) & 0xff) << 8) |
+                ((unsigned)(res_enc(v.z, h[2]) & 0xff) << 16) | ((unsigned)(res_enc(v.w, h[3]) & 0xff) << 24);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (live) __builtin_nontemporal_store(u32x4{dq[0], dq[1], dq[2], dq[3]}, reinterpret_cast<u32x4*>(d8 + base + lane * 16));
+}
+
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s) {
     if (tiled && D != 512) return hipErrorInvalidValue;
+    if (tiled) {
+        if ((long)B * Twin * L >= (1L << 31)) return hipErrorInvalidValue;
+        const long nblk = (((long)B * Twin * L + 15) >> 4) * 8;
+        hipLaunchKernelGGL(window_gather_tiled_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, conv, pe, B, P, Twin, L, shift,
+                           reinterpret_cast<signed char*>(x32), x16);
+        return hipGetLastError();
+    }
     const long total = (long)B * Twin * L * (D / 4);
     const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, shift, tiled, x32, x16);
+    hipLaunchKernelGGL(window_gather_kernel, dim3(grid), dim3(256), 0, s, conv, pe, B, P, Twin, L, D, shift, x32, x16);
     return hipGetLastError();
 }
 
