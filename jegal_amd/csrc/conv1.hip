@@ -118,10 +118,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     const int r_lo = xcd * per, r_hi = (r_lo + per < a.nstrips) ? r_lo + per : a.nstrips;
     const int s_lo = r_lo + xidx;
     // Tiles that are skipped OUTRIGHT (zmask, produced by conv1_zero_scan_kernel from the frames): a tile whose 16 input rows are
-    // zero in all 5 frames computes relu(bias) everywhere; if the tile above and the tile below are such tiles too (or do not
-    // exist), both of its pooled rows and its carry are that constant whatever the neighbours hold, so the tile needs no
-    // loads, no barrier slot and no MFMA -- its pooled rows are filled with the constant when the pool waves enter the strip.
-    // Zero tiles NEXT to a non-zero tile still run (2 bias slots, see cvt_write): their pooled rows mix with real data.
+    // zero in all 5 frames computes relu(bias) everywhere; if the tile above is such a tile too (or does not exist), both of
+    // its pooled rows and its carry are that constant whatever is below, so the tile needs no loads, no barrier slot and no
+    // MFMA -- its pooled rows are filled with the constant when the pool waves enter the strip, and the tile below takes the
+    // constant as its carry (pool(), carry_const).  A zero tile BELOW a non-zero tile still runs (2 bias slots, see
+    // cvt_write): its upper pooled row mixes with real data.
     // The walk below visits the remaining tiles of this workgroup's strips in order; all of it is wave-uniform.
     struct Walk {
         int strip, rt;
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // per-channel constant relu(bias): one LDS read instead of the 3x3 window
         // per-thread part of the output address (halves): pooled row prow, pooled column ppw, channel group pcg
         const int pthr = (prow * PW + ppw) * 64 + pcg * 8;
-        auto pool = [&](int strip, int rt, int t, bool fastz) {
+        // carry_const: the tile above was skipped outright -- nobody wrote its carry, which is the constant cz in every column
+        auto pool = [&](int strip, int rt, int t, bool fastz, bool carry_const) {
             const int nf = (int)((unsigned)strip / 5u);
             const int j = strip - nf * 5;
             const char* cbuf = smem + OFF_CONV + (t & 1) * CONV_BYTES;
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 const f16x8 q2 = at(cbuf, 2, ccg, ccol), q3 = at(cbuf, 3, ccg, ccol);
                 cnext = max8(q2, q3);
                 if (prow == 0) {            // pooled row 2rt-1: carry (conv rows 4rt-2, 4rt-1) and R0
-                    const f16x8 a0 = at(cin, 0, pcg, c0), a1 = at(cin, 0, pcg, c1), a2 = at(cin, 0, pcg, c2);
+                    const f16x8 a0 = carry_const ? cz : at(cin, 0, pcg, c0), a1 = carry_const ? cz : at(cin, 0, pcg, c1),
+                                a2 = carry_const ? cz : at(cin, 0, pcg, c2);
                     const f16x8 b0 = at(cbuf, 0, pcg, c0), b1 = at(cbuf, 0, pcg, c1), b2 = at(cbuf, 0, pcg, c2);
                     m = max8(max8(max8(a0, a1), max8(a2, b0)), max8(b1, b2));
                 } else {                    // pooled row 2rt: R0, R1, R2
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             if (ph >= 0 && j > 0 && ppw == 0) {     // export conv column 0 (vertically pooled) for strip j-1's last pooled column
                 f16x8 e;
                 if (fastz) e = m;
-                else if (prow == 0) e = max8(at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
+                else if (prow == 0) e = max8(carry_const ? cz : at(cin, 0, pcg, 0), at(cbuf, 0, pcg, 0));
                 else e = max8(max8(at(cbuf, 0, pcg, 0), at(cbuf, 1, pcg, 0)), at(cbuf, 2, pcg, 0));
                 *reinterpret_cast<f16x8*>(a.edge + (((long)nf * PH + ph) * 4 + (j - 1)) * 64 + pcg * 8) = e;
             }
@@ -463,8 +466,9 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // fastz for the tile hD: it is a zero tile and so is the tile above it (the previous tile of the walk, or a skipped
         // one, or there is none) -- every conv value in its pooling windows is then the per-channel constant
         auto pool_step = [&](int tprev) {
-            const bool above_zero = hD.rt == 0 || ((hD.skip >> (hD.rt - 1)) & 1u) || z2;
-            pool(hD.strip, hD.rt, tprev, z1 && above_zero);
+            const bool above_skipped = hD.rt > 0 && ((hD.skip >> (hD.rt - 1)) & 1u);
+            const bool above_zero = hD.rt == 0 || above_skipped || z2;
+            pool(hD.strip, hD.rt, tprev, z1 && above_zero, above_skipped);
         };
         int t = 0;
         while (!hC.done) {                      // hC = tile t
@@ -652,12 +656,13 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
 }
 
 // position nf = (clip b, padded-clip position p) reads frames clamp(p + dt - pad), dt = 0..4: a tile is all-zero for the position
-// when its band is zero in all five; it is SKIPPED when the tiles above and below are all-zero too (or do not exist), so that
-// both of its pooled rows and its carry are the constant whatever the neighbours hold.
+// when its band is zero in all five; it is SKIPPED when the tile above is all-zero too (or does not exist): both of its pooled
+// rows (2rt-1: carry of the tile above and its own row 0; 2rt: its rows 0..2) are then the constant.  Its own carry is the
+// constant as well, which the tile below -- if that one runs -- takes from cz instead of LDS (pool(), carry_const).
 // It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output are one constant row:
-// with row tiles 0..L-1 skipped (so band L is zero too) the pooled rows 0..2L hold relu(bias) in every column, and conv2
-// (5x5, stride 2, no padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-2 are identical pixel for pixel.  The
-// conv2 GEMM then computes rows >= L-2 only and row L-2 is copied upwards (launch_conv_rows_replicate); *rowskip = min (L-2).
+// with row tiles 0..L-1 skipped the pooled rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2, no
+// padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-3 are identical pixel for pixel.  The conv2 GEMM then
+// computes rows >= L-3 only and row L-3 is copied upwards (launch_conv_rows_replicate); *rowskip = min (L-3).
 __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip,
                                        int* __restrict__ rowskip) {
     const int nf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -670,11 +675,11 @@ __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int ncli
             f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
             z &= fz[b * T + f];
         }
-        const unsigned sk = z & ((z << 1) | 1u) & ((z >> 1) | (1u << (ROW_TILES - 1)));
+        const unsigned sk = z & ((z << 1) | 1u);
         skip[nf] = sk;
         const int L = __builtin_ctz(~sk);                // sk has 22 bits: L <= 22
         constexpr int C2_OH = (PH - 5) / 2 + 1;          // conv2 output rows (20)
-        rs = L >= 2 ? L - 2 : 0;
+        rs = L >= 3 ? L - 3 : 0;
         rs = rs < C2_OH ? rs : C2_OH - 1;                // an all-black position: every row is a copy of the last one
     }
 #pragma unroll
