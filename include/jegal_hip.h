@@ -142,6 +142,8 @@ int jg_asd(jg_handle* h, const float* query, const float* cand, const int32_t* c
 
 /* ---- profiling: HIP-event timing per stage on the handle's stream -------------------------- */
 enum { JG_ST_STACK = 0, JG_ST_CONV1, JG_ST_POOL, JG_ST_CONV, JG_ST_GEMM, JG_ST_ATTN, JG_ST_NORM, JG_ST_MISC, JG_ST_CONV1_AUX, JG_ST_COUNT };
+/* on: 0 = off, 1 = every launch is bracketed by two events, 2 + stage = only the launches of that stage are (the other
+ * launches of the step then run back to back, as in an unprofiled step) */
 int jg_profile_enable(jg_handle* h, int on);
 /* synchronises, then returns accumulated milliseconds and launch count of a stage since the last reset */
 int jg_profile_get(jg_handle* h, int stage, double* ms, int64_t* launches);

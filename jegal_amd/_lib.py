@@ -394,8 +394,9 @@ class Engine:
         return pred
 
     # ---- profiling
-    def profile(self, on):
-        self._ck(self.lib.jg_profile_enable(self.h, int(bool(on))))
+    def profile(self, on, only=None):
+        """on: bracket every launch with HIP events; only="conv1": bracket just that stage (the rest of the step runs back to back)."""
+        self._ck(self.lib.jg_profile_enable(self.h, 2 + STAGES.index(only) if (on and only) else int(bool(on))))
 
     def profile_reset(self):
         self._ck(self.lib.jg_profile_reset(self.h))

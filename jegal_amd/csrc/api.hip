@@ -89,6 +89,7 @@ struct jg_handle {
     EngineOpts opts;               // per-handle tuning switches + per-device resources (common.h)
     Arena ws;
     bool prof = false;
+    int prof_only = -1;            // >= 0: only this stage is bracketed with events (jg_profile_enable(h, 2 + stage))
     std::vector<ProfRec> recs;
     double prof_ms[JG_ST_COUNT] = {0};
     int64_t prof_n[JG_ST_COUNT] = {0};
@@ -134,14 +135,15 @@ struct DeviceGuard {
 template <class F>
 int timed(jg_handle* h, int stage, F&& f) {
     ProfRec r{stage, nullptr, nullptr};
-    if (h->prof) {
+    const bool prof = h->prof && (h->prof_only < 0 || h->prof_only == stage);
+    if (prof) {
         HIPCHK(h, hipEventCreate(&r.e0));
         HIPCHK(h, hipEventCreate(&r.e1));
         HIPCHK(h, hipEventRecord(r.e0, h->stream));
     }
     hipError_t e = f();
     if (e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "kernel launch failed (stage %s): %s", jg_stage_name(stage), hipGetErrorString(e));
-    if (h->prof) {
+    if (prof) {
         HIPCHK(h, hipEventRecord(r.e1, h->stream));
         h->recs.push_back(r);
     }
@@ -1224,6 +1226,8 @@ int jg_asd(jg_handle* h, const float* q, const float* cand, const int32_t* coff,
 int jg_profile_enable(jg_handle* h, int on) {
     if (!h) return JG_ERR_ARG;
     h->prof = on != 0;
+    h->prof_only = on >= 2 ? on - 2 : -1;
+    if (h->prof_only >= JG_ST_COUNT) JG_FAIL(h, JG_ERR_ARG, "bad stage");
     return JG_OK;
 }
 
