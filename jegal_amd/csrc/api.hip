@@ -80,6 +80,7 @@ struct jg_handle {
     f16* gs_qpe = nullptr;         // [21][1536]: layer-0 W_qkv pe[j] + b (Qkv0); recomputed when weights or bias corrections change
     bool gs_qpe_valid = false;
     bool qkv0_linear = true;       // layer-0 qkv projection over the distinct conv positions + gather in the attention kernel
+    bool ws_poison = false;        // option "ws_poison": fill the workspace with 0xff before every clip chunk (tests)
     bool conv2_row_skip = true;    // conv2 leaves out the leading output rows that the zero-band scan proves to be copies of one row
     const int* last_rowskip = nullptr;   // device word the last conv stack's conv2 read its row skip from (jg_debug_conv2_rowskip)
     std::map<std::string, HostTensor> host;
@@ -469,6 +470,7 @@ ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int P
     g.cshift = 0;
     while ((1 << g.cshift) < C) ++g.cshift;
     g.rowskip = nullptr;
+    g.in_rowclamp = nullptr;
     return g;
 }
 
@@ -495,7 +497,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
     ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);            // 20 x 37   (taps in parity-class order, as packed)
-    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);     // 10 x 19
+    ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);           // 10 x 19
     const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);     // 10 x 10
     const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);     // 10 x 10
     RET(wsalloc(h, (size_t)NF * 43 * 78 * 64, &p1));
@@ -514,12 +516,14 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
-        const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && NF * 20 * 37 < (1L << 24);
+        // (only the LDS-DMA conv kernel honours it: it also writes the copies of the first computed row)
+        const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && h->opts.gemm_glds && NF * 10 * 19 >= 256 &&
+                             NF * 20 * 37 < (1L << 24);      // conv2 and conv3 both on the LDS-DMA conv kernel
         RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr, !rowskip));
         // the zero-band scan also knows how many leading rows of conv2's output are copies of one row (conv1.hip,
-        // conv1_skip_mask_kernel): conv2 computes the others, launch_conv_rows_replicate fills them in
+        // conv1_skip_mask_kernel): conv2 computes the others, conv3 reads the first computed row in their place
         if (rowskip)
-            g2.rowskip = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
+            g2.rowskip = g3.in_rowclamp = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -531,7 +535,6 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     }
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
-    if (g2.rowskip) RET(timed(h, JG_ST_CONV, [&] { return launch_conv_rows_replicate(o2, (int)NF, g2.OH, g2.OW, 128, g2.rowskip, h->stream); }));
     h->last_rowskip = g2.rowskip;
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
@@ -630,6 +633,8 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
     for (int b0 = 0; b0 < B; b0 += h->chunk) {
         const int nb = std::min(h->chunk, B - b0);
         h->ws.reset();
+        if (h->ws_poison)                       // test aid: whatever a kernel reads without having written it is NaN
+            for (auto& c : h->ws.chunks) HIPCHK(h, hipMemsetAsync(c.p, 0xff, c.cap, h->stream));
         float* conv;
         RET(wsalloc(h, (size_t)nb * P * 512, &conv));
         const char* src = reinterpret_cast<const char*>(frames) + (size_t)b0 * sb * esz;
@@ -973,6 +978,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "qkv0_linear")) { h->qkv0_linear = value != 0; return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }

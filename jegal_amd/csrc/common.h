@@ -23,11 +23,14 @@ struct ConvGeom {
     // use the same order (api.hip:make_conv).
     unsigned long long taps[4];
     int tap_table;
-    // Optional (LDS-DMA conv kernels only; others ignore it and compute every row): device pointer to the number of LEADING
+    // Optional (LDS-DMA conv kernels ONLY: set it for launches that take that path, api.hip): device pointer to the number of LEADING
     // output rows of every image that are NOT computed -- the caller knows them to be copies of the first computed row
-    // (conv2 behind conv1's zero-band skip, conv1.hip) and fills them with launch_conv_rows_replicate.  Read by the kernel
-    // at launch: the host never sees the value (no synchronisation).  nullptr: every row is computed.
+    // (conv2 behind conv1's zero-band skip, conv1.hip) and makes the consumer read that row instead (in_rowclamp).  Read by
+    // the kernel at launch: the host never sees the value (no synchronisation).  nullptr: every row is computed.
     const int* rowskip;
+    // Optional, the consumer's side of it (LDS-DMA conv instances with fewer than 512 rows per tile): device pointer to the number of leading INPUT
+    // rows of every image that were left out by the producer; the loader reads row *in_rowclamp in their place.
+    const int* in_rowclamp;
 };
 constexpr int CONV1_ZHDR_WORDS = 64;        // header of conv1's zero-scan scratch: 32 words of zconst, then ...
 constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's constant leading rows - 1
@@ -142,7 +145,6 @@ hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long position
 size_t conv1_zmask_elems(int nclip, int T);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
-hipError_t launch_conv_rows_replicate(f16* out, int nimg, int OH, int OW, int C, const int* rowskip, hipStream_t s);
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s);
 hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
 // It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output are one constant row:
 // with row tiles 0..L-1 skipped the pooled rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2, no
 // padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-3 are identical pixel for pixel.  The conv2 GEMM then
-// computes rows >= L-3 only and row L-3 is copied upwards (launch_conv_rows_replicate); *rowskip = min (L-3).
+// computes rows >= L-3 only and conv3 reads row L-3 in place of the rows above it (ConvGeom::in_rowclamp); *rowskip = min (L-3).
 __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip,
                                        int* __restrict__ rowskip) {
     const int nf = blockIdx.x * blockDim.x + threadIdx.x;

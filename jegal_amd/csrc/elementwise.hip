@@ -110,26 +110,6 @@ hipError_t launch_pe_project(const float* pe, int S, const f16* Wh, const f16* W
     return hipGetLastError();
 }
 
-// Rows 0..*rowskip-1 of every (OH, OW, C) image <- row *rowskip of the same image (ConvGeom::rowskip: the conv kernel left them
-// out because they are copies of that row).  One workgroup per (image, 2 KB slice of the row); *rowskip == 0: nothing to do.
-__global__ __launch_bounds__(128) void conv_rows_replicate_kernel(f16* __restrict__ out, int OH, long row_halves, const int* __restrict__ rowskip) {
-    const int rs = *rowskip;
-    if (rs <= 0 || rs >= OH) return;
-    const long v = (long)blockIdx.y * 128 + threadIdx.x;              // 16-byte vector of the row
-    if (v * 8 >= row_halves) return;
-    f16* img = out + (long)blockIdx.x * OH * row_halves + v * 8;
-    const f16x8 r = *reinterpret_cast<const f16x8*>(img + (long)rs * row_halves);
-    for (int oh = 0; oh < rs; ++oh) __builtin_nontemporal_store(r, reinterpret_cast<f16x8*>(img + (long)oh * row_halves));
-}
-
-hipError_t launch_conv_rows_replicate(f16* out, int nimg, int OH, int OW, int C, const int* rowskip, hipStream_t s) {
-    if (nimg <= 0 || !rowskip) return hipSuccess;
-    const long row_halves = (long)OW * C;
-    if (row_halves % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_rows_replicate_kernel, dim3((unsigned)nimg, (unsigned)((row_halves / 8 + 127) / 128)), dim3(128), 0, s, out, OH, row_halves, rowskip);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------
 // Window gather + positional encoding (gestsync.py:152, windowing of inference_embs.py:488-492):
 // x[(b,i,j)][:] = conv[b][clamp(i+j-shift, 0, P-1)][:] + pe[j][:]   i < Twin, j < L.  conv is (B,P,D) fp32.

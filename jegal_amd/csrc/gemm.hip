@@ -243,6 +243,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
         }
     }
+    // ConvGeom::in_rowclamp (every conv instance but the 512x128 one, which has no register to spare): input rows 0..rcl-1 of every
+    // image are never read -- they are copies of row rcl (the producer left them out, ConvGeom::rowskip) -- the loader reads
+    // row rcl in their place
+    constexpr bool ROWCLAMP = CONV && BM != 512;
+    int rcl = 0;
+    if constexpr (ROWCLAMP) {
+        if (a.g.in_rowclamp) {
+            rcl = __builtin_amdgcn_readfirstlane(*a.g.in_rowclamp);
+            rcl = rcl > 0 && rcl < a.g.H ? rcl : 0;
+        }
+    }
     auto row_full = [&](int m) -> long {
         if (!CONV || rsk == 0) return m;
         int img = (int)((float)m * inv_perc);
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const int ih = (xpix[i] >> 16) + stkh, iw = (int)(short)(xpix[i] & 0xffff) + stkw;
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
+                if (ROWCLAMP && ok && ih < rcl) src += (long)(rcl - ih) * (a.g.W * a.g.C);
             } else {
                 src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }

@@ -200,7 +200,12 @@ def test_conv2_row_skip_follows_the_zero_bands(engine, models):
     e = np.zeros((2, T, 270, 480, 3), dtype=np.uint8); cases.append((e, 19))                # black clips: every row is the constant row
     for clips, want in cases:
         frames = torch.from_numpy(clips).cuda()
-        out = engine.extract_gesture(frames)
+        engine.set_option("ws_poison", 1)           # rows that the skips leave unwritten are NaN: reading one would show
+        try:
+            out = engine.extract_gesture(frames).clone()
+        finally:
+            engine.set_option("ws_poison", 0)
+        assert torch.isfinite(out).all()
         got = engine.debug_conv2_rowskip()
         engine.set_option("conv2_row_skip", 0)
         try:
