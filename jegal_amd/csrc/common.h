@@ -28,7 +28,7 @@ struct ConvGeom {
     // (conv2 behind conv1's zero-band skip, conv1.hip) and makes the consumer read that row instead (in_rowclamp).  Read by
     // the kernel at launch: the host never sees the value (no synchronisation).  nullptr: every row is computed.
     const int* rowskip;
-    // Optional, the consumer's side of it (LDS-DMA conv instances with fewer than 512 rows per tile): device pointer to the number of leading INPUT
+    // Optional, the consumer's side of it (LDS-DMA conv kernel; launch_glds picks the instances with the clamp): device pointer to the number of leading INPUT
     // rows of every image that were left out by the producer; the loader reads row *in_rowclamp in their place.
     const int* in_rowclamp;
 };

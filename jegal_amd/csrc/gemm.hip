@@ -243,10 +243,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
         }
     }
-    // ConvGeom::in_rowclamp (every conv instance but the 512x128 one, which has no register to spare): input rows 0..rcl-1 of every
-    // image are never read -- they are copies of row rcl (the producer left them out, ConvGeom::rowskip) -- the loader reads
-    // row rcl in their place
-    constexpr bool ROWCLAMP = CONV && BM != 512;
+    // ConvGeom::in_rowclamp (conv instances with SPR, which has no other meaning for CONV: launch_glds picks them when the pointer
+    // is set): input rows 0..rcl-1 of every image are never read -- they are copies of row rcl (the producer left them out,
+    // ConvGeom::rowskip) -- the loader reads row rcl in their place.  Its own instances: the compare + select + 64-bit add per
+    // LDS-DMA piece cost the 256x256 conv kernel 5 % (conv4 / conv5: 580 -> 610 us) when it was compiled into all of them.
+    constexpr bool ROWCLAMP = CONV && SPR;
     int rcl = 0;
     if constexpr (ROWCLAMP) {
         if (a.g.in_rowclamp) {
@@ -905,6 +906,15 @@ static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_
     // 128x128 tiles (32x64 wave tiles) give 4x the workgroups
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
+    if constexpr (CONV) {
+        if (a.g.in_rowclamp) {               // consumer of a row-skipping producer (conv3): the instances with the clamp in their loader
+            if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, true, 2, 4, 2, true>(a, o, s);
+            if constexpr (!W2) {
+                if (o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, true, 8, 2, 4, true>(a, o, s);
+            }
+            return launch_glds_cfg<W2, true, 4, 4, 2, true>(a, o, s);
+        }
+    }
     if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, o, s);
     if constexpr (!W2) {
         if (o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0) {
