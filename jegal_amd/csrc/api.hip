@@ -111,6 +111,13 @@ struct jg_handle {
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
     size_t feats_cap = 0;
+    // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
+    // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
+    // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
+    bool dual_stream = true;
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    Arena lane_ws[2];
+    hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};      // [0]: the caller's stream at entry, [1], [2]: end of each lane
 };
 
 namespace {
@@ -941,6 +948,8 @@ int jg_destroy(jg_handle* h) {
         if (h->feats) hipFree(h->feats);
         if (h->gs_qpe) hipFree(h->gs_qpe);
         h->ws.release();
+        for (int l = 0; l < 2; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]); }
+        for (int e = 0; e < 3; ++e) if (h->lane_ev[e]) hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
@@ -979,6 +988,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
     if (!std::strcmp(name, "qkv0_linear")) { h->qkv0_linear = value != 0; return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }
@@ -1192,14 +1202,45 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
     // the (B,T,1024) GestSync features stay on the device in a buffer owned by the handle
     const size_t need_b = (size_t)B * T * 1024 * sizeof(float);
     if (need_b > h->feats_cap) {
-        if (h->feats) { HIPCHK(h, hipStreamSynchronize(h->stream)); HIPCHK(h, hipFree(h->feats)); h->feats = nullptr; h->feats_cap = 0; }
+        if (h->feats) { HIPCHK(h, hipDeviceSynchronize()); HIPCHK(h, hipFree(h->feats)); h->feats = nullptr; h->feats_cap = 0; }
         HIPCHK(h, hipMalloc(&h->feats, need_b));
         h->feats_cap = need_b;
     }
-    RET(gestsync_clip_impl(h, frames, dtype, B, T, h->feats));
-    h->ws.reset();
-    RET(jegal_gestures_impl(h, h->feats, nullptr, B, T, 1, out_emb));
-    return timed(h, JG_ST_MISC, [&] { return launch_l2norm(out_emb, out_emb, B * T, 512, h->stream); });
+    auto run_part = [&](int b0, int nb) -> int {
+        const size_t esz = dtype == JG_U8 ? 1 : 4;
+        const char* fr = reinterpret_cast<const char*>(frames) + (size_t)b0 * T * FH * FW * 3 * esz;
+        float* feats = h->feats + (size_t)b0 * T * 1024;
+        float* emb = out_emb + (size_t)b0 * T * 512;
+        RET(gestsync_clip_impl(h, fr, dtype, nb, T, feats));
+        h->ws.reset();
+        RET(jegal_gestures_impl(h, feats, nullptr, nb, T, 1, emb));
+        return timed(h, JG_ST_MISC, [&] { return launch_l2norm(emb, emb, nb * T, 512, h->stream); });
+    };
+    // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
+    // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
+    if (!h->dual_stream || B < 8 || (long)((B * 3 + 4) / 8) * T < 256) return run_part(0, B);
+    // ---- two lanes.  Entry: both lane streams wait for the caller's stream (the frames); exit: the caller's stream waits for
+    // both lanes (the embeddings).  h->stream / h->ws are the current lane's while its launches are enqueued.
+    for (int l = 0; l < 2; ++l)
+        if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    for (int e = 0; e < 3; ++e)
+        if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
+    hipStream_t user = h->stream;
+    HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
+    const int B0 = (B * 3 + 4) / 8;
+    int rc = JG_OK;
+    for (int l = 0; l < 2 && rc == JG_OK; ++l) {
+        if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
+        h->stream = h->lane_stream[l];
+        std::swap(h->ws, h->lane_ws[l]);
+        rc = l == 0 ? run_part(0, B0) : run_part(B0, B - B0);
+        std::swap(h->ws, h->lane_ws[l]);
+        h->stream = user;
+        if (rc == JG_OK && (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess ||
+                            hipStreamWaitEvent(user, h->lane_ev[1 + l], 0) != hipSuccess)) rc = JG_ERR_HIP;
+    }
+    if (rc == JG_ERR_HIP && h->err.empty()) h->err = "lane stream / event call failed";
+    return rc;
 }
 
 int jg_pool_mean(jg_handle* h, const float* x, const int32_t* off, int n, int D, float* out) {
@@ -1267,6 +1308,6 @@ int jg_profile_reset(jg_handle* h) {
     return JG_OK;
 }
 
-int64_t jg_workspace_bytes(jg_handle* h) { return h ? (int64_t)h->ws.total() : 0; }
+int64_t jg_workspace_bytes(jg_handle* h) { return h ? (int64_t)(h->ws.total() + h->lane_ws[0].total() + h->lane_ws[1].total()) : 0; }
 
 }  // extern "C"

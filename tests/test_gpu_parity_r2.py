@@ -89,7 +89,7 @@ def test_jegal_text_long_sequences(models, oracle_sd, L):
 
 # ------------------------------------------------------------------ (b) every A/B switch and W2_ALL
 OPTIONS = ["attn_mfma", "fuse_ln", "gemm_glds", "gemm_persistent", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile",
-           "gemm_counted", "conv1_zero_skip", "conv2_row_skip", "qkv0_linear", "conv1_direct", "edge_dedup"]
+           "gemm_counted", "conv1_zero_skip", "conv2_row_skip", "qkv0_linear", "conv1_direct", "edge_dedup", "dual_stream"]
 
 
 @pytest.fixture(scope="module")
@@ -121,7 +121,7 @@ def test_every_option_stays_within_tolerance(engine, models, option_case, opt):
     e_base, e_alt = rel(base, ref), rel(alt, ref)
     print(f"{opt}=0: rel {e_alt:.3e} (default {e_base:.3e}); |alt - default| rel {rel(alt, base):.3e}")
     assert e_base < TOL and e_alt < TOL
-    if opt in ("conv1_zero_skip", "conv2_row_skip", "edge_dedup", "gemm_persistent", "gemm_counted"):
+    if opt in ("conv1_zero_skip", "conv2_row_skip", "edge_dedup", "gemm_persistent", "gemm_counted", "dual_stream"):
         assert torch.equal(alt, base), f"{opt} only changes scheduling / skips exact zeros: must be bit-identical"
 
 
@@ -215,6 +215,37 @@ def test_conv2_row_skip_follows_the_zero_bands(engine, models):
             engine.set_option("conv2_row_skip", 1)
         assert got == want, (got, want)
         assert torch.equal(out, ref)
+
+
+def test_dual_stream_lanes_are_bit_identical_and_stream_ordered(engine, models):
+    """jg_extract_gesture runs batches of >= 8 clips as two parts on two internal streams.  Same bits as one stream; the
+    caller's stream is joined on both sides: frames produced on a side stream just before the call and embeddings consumed
+    right after it, without any host synchronisation, must behave as with a single stream."""
+    B, T = 16, 50                              # parts of 6 and 10 clips
+    host = synth.synth_frames(777, B, T)
+    frames = torch.from_numpy(host).cuda()
+    engine.set_option("dual_stream", 0)
+    try:
+        ref = engine.extract_gesture(frames).clone()
+    finally:
+        engine.set_option("dual_stream", 1)
+    engine.set_option("ws_poison", 1)
+    try:
+        out = engine.extract_gesture(frames).clone()
+    finally:
+        engine.set_option("ws_poison", 0)
+    assert torch.equal(out, ref)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    pinned = torch.from_numpy(host).pin_memory()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            dev = torch.empty_like(frames)
+            dev.copy_(pinned, non_blocking=True)                 # the call must wait for this copy ...
+            emb = engine.extract_gesture(dev)
+            s = emb.double().sum()                                # ... and this reduction for the two lanes
+        total = float(s.item())
+    assert total == float(ref.double().sum().item())
 
 
 def test_conv1_call_sequence_stress(engine, models):
