@@ -115,6 +115,7 @@ struct jg_handle {
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
     bool dual_stream = true;
+    int dual_split = 3;            // the first lane gets dual_split/8 of the batch
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     Arena lane_ws[2];
     hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};      // [0]: the caller's stream at entry, [1], [2]: end of each lane
@@ -989,6 +990,11 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "dual_split")) {
+        if (value < 1 || value > 7) JG_FAIL(h, JG_ERR_ARG, "dual_split must be 1..7 (eighths of the batch on the first lane)");
+        h->dual_split = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "qkv0_linear")) { h->qkv0_linear = value != 0; return JG_OK; }
     if (!std::strcmp(name, "attn_mfma")) { o.attn_mfma = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_glds")) { o.gemm_glds = value != 0; return JG_OK; }
@@ -1218,7 +1224,7 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
     };
     // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
     // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
-    if (!h->dual_stream || B < 8 || (long)((B * 3 + 4) / 8) * T < 256) return run_part(0, B);
+    if (!h->dual_stream || B < 8 || (long)((B * h->dual_split + 4) / 8) * T < 256) return run_part(0, B);
     // ---- two lanes.  Entry: both lane streams wait for the caller's stream (the frames); exit: the caller's stream waits for
     // both lanes (the embeddings).  h->stream / h->ws are the current lane's while its launches are enqueued.
     for (int l = 0; l < 2; ++l)
@@ -1227,7 +1233,7 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
         if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
     hipStream_t user = h->stream;
     HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
-    const int B0 = (B * 3 + 4) / 8;
+    const int B0 = (B * h->dual_split + 4) / 8;
     int rc = JG_OK;
     for (int l = 0; l < 2 && rc == JG_OK; ++l) {
         if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
