@@ -8,6 +8,10 @@ collective on the data path.  After the timed loop every rank takes part in ONE 
 evaluation (seed-1237 gallery of 10 000 clips, queries sharded ceil(N/G) per rank, gallery assembled by an
 all-gather: RCCL over xGMI) whose R@K / MR must equal the single-rank result.
 
+`value` is measured with the engine's default scheduling: every batch runs as two parts on two internal HIP streams
+(option dual_stream, bit-identical results).  The `roofline*` objects and `stage_ms_per_step` time the kernels on ONE stream
+(a kernel's roofline is a property of the kernel running alone); `single_stream` repeats the timed loop in that mode.
+
 Usage: python bench.py [--gpus N --steps K --warmup W]
   N > 1 without a torchrun environment: this process starts N fresh rank processes itself (it makes no GPU
   call before or after doing so) and relays rank 0's JSON line.  Under `python -m torch.distributed.run
