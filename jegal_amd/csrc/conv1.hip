@@ -13,14 +13,17 @@
 //   waves 0-3  MFMA waves.  Each keeps the complete K=784 weight panel of 32 output channels in
 //              196 VGPRs for the whole kernel (weights are the MFMA A operand, never re-read) and per
 //              tile computes two 32-position x 32-channel blocks; per k-step ONE ds_read_b128 (the
-//              patch fragment, MFMA B operand) feeds one MFMA, 4 fragments in flight (order pinned
+//              patch fragment, MFMA B operand) feeds one MFMA, 6 fragments in flight (order pinned
 //              with sched_barrier).  Epilogue: scale, ReLU, fp16 -> LDS conv buffer (ds_write_b64).
-//   waves 4-7  loader/pool waves.  (a) read the 5 source frames of the tile after next straight
-//              from the u8 HWC video (dword loads, kept in registers across the barrier), (b) pool
-//              the previous tile's conv rows from the LDS conv buffer and store the pooled rows
-//              (16-B stores, full 128-B lines per pooled pixel), (c) convert the next tile's u8 -> fp16
-//              exactly (0..255 are exact; the 1/255 is applied in fp32 in the epilogue) and write its
-//              32-byte pixel slots.  Their VALU/VMEM/LDS work overlaps the matrix work on the same SIMDs.
+//   waves 4-7  loader/pool waves.  (a) read the 5 source frames of the tile three ahead straight
+//              from the u8 HWC video (inline-asm dwordx3 loads with hand-counted waits, two register
+//              sets), (b) pool the previous tile's conv rows from the LDS conv buffer and store the
+//              pooled rows (16-B nontemporal stores), (c) turn the next tile's u8 into fp16 by byte
+//              placement (n -> the subnormal n * 2^-24, exact; the 2^24/255 rides in the epilogue scale)
+//              and write its 32-byte pixel slots.  Their VALU/VMEM/LDS work overlaps the matrix work.
+// Zero input bands (the reference blanks the face rows): conv1_zero_scan_kernel + conv1_skip_mask_kernel find
+// them before the launch; tiles whose band and upper neighbour are zero are skipped outright (constant
+// fill), and the same scan tells conv2 how many of its leading output rows are copies of one row.
 // Tile = 4 conv rows x 32 conv cols of one position (16 input rows x 100 pixel slots), double
 // buffered, one barrier per tile.  A workgroup marches DOWN a 32-column strip (22 tiles), so the
 // vertical 3x3/s2 pooling window that straddles two tiles is served by a one-row carry
@@ -740,8 +743,7 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     if (a.zskip && zscratch && nclip * T > 0 && (a.nstrips + num_cu - 1) / num_cu + 8 <= MAX_WG_STRIPS) {
         a.zmask = zscratch + CONV1_ZHDR_WORDS + (size_t)nclip * T;
         a.zconst = reinterpret_cast<const f16*>(zscratch);
-        static const bool env_fill_all = getenv("JG_CONV1_FILL_ALL") != nullptr;      // A/B aid
-        if (!fill_all && !env_fill_all) a.fill_from = reinterpret_cast<const int*>(zscratch) + CONV1_ROWSKIP_WORD;
+        if (!fill_all) a.fill_from = reinterpret_cast<const int*>(zscratch) + CONV1_ROWSKIP_WORD;
     }
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;
