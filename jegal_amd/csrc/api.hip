@@ -98,6 +98,9 @@ struct jg_handle {
     // GestSync
     bool gs_ready = false;
     Lin c1, c2, c3, c4, c5, fc6, ff0, ff2;
+    // const chain: what conv2 / conv3 / conv4 compute from an all-constant pooled image (relu(bias1) everywhere) -- the rows of
+    // their outputs that the zero-band skip makes position-independent are read from here (ConvGeom::const_in); 4 copies each
+    f16 *gs_c2C = nullptr, *gs_c3C = nullptr, *gs_c4C = nullptr;
     float* c1_scale255 = nullptr;
     f16* c1_direct = nullptr;      // conv1 weights, slot-major [49][64][16] for the direct kernel
     float* gs_pe = nullptr;
@@ -477,8 +480,9 @@ ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int P
     g.OW = (W + 2 * PW - KW) / SW + 1;
     g.cshift = 0;
     while ((1 << g.cshift) < C) ++g.cshift;
-    g.rowskip = nullptr;
-    g.in_rowclamp = nullptr;
+    g.rowskip = nullptr; g.rowskip_op = 0;
+    g.in_rowskip = nullptr; g.in_op = 0;
+    g.const_in = nullptr;
     return g;
 }
 
@@ -506,8 +510,8 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
     ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);            // 20 x 37   (taps in parity-class order, as packed)
     ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);           // 10 x 19
-    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);     // 10 x 10
-    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);     // 10 x 10
+    ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);           // 10 x 10
+    ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);           // 10 x 10
     RET(wsalloc(h, (size_t)NF * 43 * 78 * 64, &p1));
     RET(wsalloc(h, (size_t)NF * 20 * 37 * 128, &o2));
     RET(wsalloc(h, (size_t)NF * 10 * 19 * 256, &o3));
@@ -524,14 +528,19 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
-        // (only the LDS-DMA conv kernel honours it: it also writes the copies of the first computed row)
-        const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && h->opts.gemm_glds && NF * 10 * 19 >= 256 &&
-                             NF * 20 * 37 < (1L << 24);      // conv2 and conv3 both on the LDS-DMA conv kernel
+        // Position-independent leading rows (common.h, ConvGeom::rowskip): the zero-band scan leaves conv2's count in zscr;
+        // conv2 / conv3 / conv4 leave those rows out and conv3 / conv4 / conv5 read them from the const chain.  Only the
+        // LDS-DMA conv kernel knows how, so every layer of the chain must take that path.
+        const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && h->opts.gemm_glds && h->gs_c2C && NF * 10 * 10 >= 256 &&
+                             NF * 20 * 37 < (1L << 24);
         RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr, !rowskip));
-        // the zero-band scan also knows how many leading rows of conv2's output are copies of one row (conv1.hip,
-        // conv1_skip_mask_kernel): conv2 computes the others, conv3 reads the first computed row in their place
-        if (rowskip)
-            g2.rowskip = g3.in_rowclamp = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
+        if (rowskip) {
+            const int* w = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
+            g2.rowskip = w; g2.rowskip_op = 0;
+            g3.rowskip = w; g3.rowskip_op = 1; g3.in_rowskip = w; g3.in_op = 0; g3.const_in = h->gs_c2C;
+            g4.rowskip = w; g4.rowskip_op = 2; g4.in_rowskip = w; g4.in_op = 1; g4.const_in = h->gs_c3C;
+            g5.in_rowskip = w; g5.in_op = 2; g5.const_in = h->gs_c4C;
+        }
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
@@ -550,6 +559,36 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream); }));
     e.out16 = conv16; e.out32 = conv_out;
     RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
+    return JG_OK;
+}
+
+// Const chain (ConvGeom::rowskip): conv2 / conv3 / conv4 of an all-constant pooled image -- relu(bias1) in every pixel, which is
+// what conv1 + max-pool produce wherever the frames are blanked.  Computed once per weight load with the run-time kernels
+// (same MFMA sequence per output element, so the rows are bit-identical to what the layers would compute per position);
+// 4 copies per layer so that every launch has the 256 rows the LDS-DMA kernel needs.
+int gs_build_const_chain(jg_handle* h) {
+    h->gs_c2C = h->gs_c3C = h->gs_c4C = nullptr;
+    if (!h->opts.gemm_glds) return JG_OK;
+    constexpr int NC = 4;
+    f16 *zc, *poolC, *c2C, *c3C, *c4C;
+    h->wallocs = &h->wallocs_gs;
+    RET(walloc(h, (size_t)64, &zc));
+    RET(walloc(h, (size_t)NC * 43 * 78 * 64, &poolC));
+    RET(walloc(h, (size_t)NC * 20 * 37 * 128, &c2C));
+    RET(walloc(h, (size_t)NC * 10 * 19 * 256, &c3C));
+    RET(walloc(h, (size_t)NC * 10 * 10 * 256, &c4C));
+    HIPCHK(h, launch_conv1_zconst(h->c1_direct, 1.0f / 255.0f, zc, h->stream));
+    HIPCHK(h, launch_broadcast_channels(zc, 64, poolC, (long)NC * 43 * 78, h->stream));
+    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);
+    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);
+    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);
+    Epi e;
+    e.relu = 1;
+    e.out16 = c2C; RET(gemm(h, JG_ST_CONV, poolC, 0, NC * 20 * 37, h->c2, e, &g2));
+    e.out16 = c3C; RET(gemm(h, JG_ST_CONV, c2C, 0, NC * 10 * 19, h->c3, e, &g3));
+    e.out16 = c4C; RET(gemm(h, JG_ST_CONV, c3C, 0, NC * 10 * 10, h->c4, e, &g4));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->gs_c2C = c2C; h->gs_c3C = c3C; h->gs_c4C = c4C;
     return JG_OK;
 }
 
@@ -1046,7 +1085,7 @@ int jg_load_tensor(jg_handle* h, const char* name, const void* data, const int64
 int jg_finalize_weights(jg_handle* h, int which) {
     ENTER(h);
     h->gs_qpe_valid = false;
-    if (which & 1) RET(finalize_gestsync(h));
+    if (which & 1) { RET(finalize_gestsync(h)); RET(gs_build_const_chain(h)); }
     if (which & 2) RET(finalize_jegal(h));
     // the fp32 host copies of the checkpoint (incl. the unused audio/LSTM tensors of gestsync.py:23-32) are no longer
     // needed: packed device weights + the w32/b32 of the bias-corrected layers carry everything

@@ -23,17 +23,26 @@ struct ConvGeom {
     // use the same order (api.hip:make_conv).
     unsigned long long taps[4];
     int tap_table;
-    // Optional (LDS-DMA conv kernels ONLY: set it for launches that take that path, api.hip): device pointer to the number of LEADING
-    // output rows of every image that are NOT computed -- the caller knows them to be copies of the first computed row
-    // (conv2 behind conv1's zero-band skip, conv1.hip) and makes the consumer read that row instead (in_rowclamp).  Read by
-    // the kernel at launch: the host never sees the value (no synchronisation).  nullptr: every row is computed.
-    const int* rowskip;
-    // Optional, the consumer's side of it (LDS-DMA conv kernel; launch_glds picks the instances with the clamp): device pointer to the number of leading INPUT
-    // rows of every image that were left out by the producer; the loader reads row *in_rowclamp in their place.
-    const int* in_rowclamp;
+    // ---- position-independent leading rows (LDS-DMA conv kernels ONLY: api.hip sets these for launches that take that path).
+    // Behind conv1's zero-band skip (conv1.hip) the first rows of every layer's output do not depend on the position at all:
+    // they are what the layer computes from an all-constant input image, and the engine keeps those images per weight load
+    // ("const chain", api.hip).  A layer then leaves its first s rows out (rowskip) and its consumer reads the rows below s_in
+    // from the const image of its input instead (in_rowskip / const_in).  s = conv_skip_decode(*word, op): all layers share
+    // ONE device word (conv2's count, reduced over the launch by conv1_skip_mask_kernel) and derive their own count from it;
+    // the kernels read it at launch, the host never sees the value (no synchronisation).  nullptr: nothing is skipped.
+    const int* rowskip;       // producer side: leading output rows of every image that are NOT computed
+    int rowskip_op;
+    const int* in_rowskip;    // consumer side: leading INPUT rows of every image that were not computed by the producer ...
+    int in_op;
+    const f16* const_in;      // ... and the const image [H][W][C] of the input they are read from instead
 };
+// op 0: conv2 (the word itself); op 1: conv3 (3x3, stride 2, pad 1: rows whose window ends below s2); op 2: conv4 (stride 1, pad 1)
+__host__ __device__ inline int conv_skip_decode(int w, int op) {
+    const int s3 = w / 2;
+    return op == 0 ? w : op == 1 ? s3 : (s3 > 0 ? s3 - 1 : 0);
+}
 constexpr int CONV1_ZHDR_WORDS = 64;        // header of conv1's zero-scan scratch: 32 words of zconst, then ...
-constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's constant leading rows - 1
+constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's position-independent leading rows
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void tap_decode(const ConvGeom& g, int p, int& kh, int& kw) {
@@ -142,6 +151,8 @@ hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, cons
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
                                f16* out_pooled, f16* edge, const unsigned* zscratch, bool fill_all, const EngineOpts& o, hipStream_t s);
 hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long positions, hipStream_t s);
+// the 64 per-channel values relu(bias) that conv1 produces over an all-zero patch, as the kernel rounds them (-> const chain)
+hipError_t launch_conv1_zconst(const f16* Wd, float scale, f16* zconst, hipStream_t s);
 size_t conv1_zmask_elems(int nclip, int T);
 size_t conv1_edge_elems(long positions);
 hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
@@ -167,6 +178,7 @@ hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, h
 hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
+hipError_t launch_broadcast_channels(const f16* v, int C, f16* out, long pixels, hipStream_t s);
 hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s);
 hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s);
 size_t col_sum_scratch_elems(int K);

@@ -617,6 +617,17 @@ __global__ void conv1_edge_fix_kernel(f16* __restrict__ out, const f16* __restri
 //   3. band flags -> 22-bit mask.
 // Block 0 also computes the constant every all-zero patch produces: relu(bias) as the MFMA path rounds it (conv1 bias = the
 // hi+lo pair on the pad lane of slots 0 and 1, times 2^-24; both products and their sum are exact in fp32).
+// relu(bias) of channel c as the MFMA path rounds it: the bias is the hi+lo pair on the pad lane of slots 0 and 1, times the pad
+// lane's "1.0" = 2^-24; both products and their sum are exact in fp32
+__device__ __forceinline__ f16 conv1_zero_patch_value(const f16* __restrict__ Wd, float scale, int c) {
+    const float hi = (float)Wd[(0 * 64 + c) * 16 + 15], lo = (float)Wd[(1 * 64 + c) * 16 + 15];
+    const float acc = hi * 5.9604644775390625e-8f + lo * 5.9604644775390625e-8f;
+    return (f16)fmaxf(acc * scale, 0.f);
+}
+__global__ void conv1_zconst_kernel(const f16* __restrict__ Wd, float scale, f16* __restrict__ zconst) {
+    if (threadIdx.x < 64) zconst[threadIdx.x] = conv1_zero_patch_value(Wd, scale, threadIdx.x);
+}
+
 __device__ __forceinline__ int* zmask_hdr(f16* zconst) { return reinterpret_cast<int*>(zconst); }   // zconst = word 0 of the header
 
 __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __restrict__ src, unsigned* __restrict__ zmask,
@@ -649,11 +660,7 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
         const unsigned long long m = __builtin_amdgcn_ballot_w64(z);
         if (lane == 0) zmask[blockIdx.x] = (unsigned)m & ((1u << ROW_TILES) - 1u);
     }
-    if (blockIdx.x == 0 && tid < 64) {
-        const float hi = (float)Wd[(0 * 64 + tid) * 16 + 15], lo = (float)Wd[(1 * 64 + tid) * 16 + 15];
-        const float acc = hi * 5.9604644775390625e-8f + lo * 5.9604644775390625e-8f;          // 2^-24: the pad lane's "1.0"
-        zconst[tid] = (f16)fmaxf(acc * scale, 0.f);
-    }
+    if (blockIdx.x == 0 && tid < 64) zconst[tid] = conv1_zero_patch_value(Wd, scale, tid);
     // reset the launch-wide minimum that conv1_skip_mask_kernel (next on the stream) reduces into
     if (blockIdx.x == 0 && tid == 64) zmask_hdr(zconst)[CONV1_ROWSKIP_WORD] = 0x7fffffff;
 }
@@ -662,10 +669,11 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
 // when its band is zero in all five; it is SKIPPED when the tile above is all-zero too (or does not exist): both of its pooled
 // rows (2rt-1: carry of the tile above and its own row 0; 2rt: its rows 0..2) are then the constant.  Its own carry is the
 // constant as well, which the tile below -- if that one runs -- takes from cz instead of LDS (pool(), carry_const).
-// It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output are one constant row:
-// with row tiles 0..L-1 skipped the pooled rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2, no
-// padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-3 are identical pixel for pixel.  The conv2 GEMM then
-// computes rows >= L-3 only and conv3 reads row L-3 in place of the rows above it (ConvGeom::in_rowclamp); *rowskip = min (L-3).
+// It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output do not depend on the
+// position: with row tiles 0..L-1 skipped the pooled rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2,
+// no padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-3 are what conv2 computes from an all-constant image.
+// The conv2 GEMM then computes rows >= L-2 only, and so on down the stack (ConvGeom::rowskip, the const chain of api.hip);
+// *rowskip = min (L-2).
 __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip,
                                        int* __restrict__ rowskip) {
     const int nf = blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,8 +690,8 @@ __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int ncli
         skip[nf] = sk;
         const int L = __builtin_ctz(~sk);                // sk has 22 bits: L <= 22
         constexpr int C2_OH = (PH - 5) / 2 + 1;          // conv2 output rows (20)
-        rs = L >= 3 ? L - 3 : 0;
-        rs = rs < C2_OH ? rs : C2_OH - 1;                // an all-black position: every row is a copy of the last one
+        rs = L >= 2 ? L - 2 : 0;
+        rs = rs < C2_OH ? rs : C2_OH - 1;                // an all-black position: conv2 still computes its last row
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -712,6 +720,11 @@ hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, cons
 
 // zscratch: filled by launch_conv1_scan (nullptr: no tile is skipped outright).  The 4 pooled columns that straddle two strips
 // are closed afterwards by launch_conv1_edge_fix.
+hipError_t launch_conv1_zconst(const f16* Wd, float scale, f16* zconst, hipStream_t s) {
+    hipLaunchKernelGGL(conv1_zconst_kernel, dim3(1), dim3(64), 0, s, Wd, scale * 16777216.0f, zconst);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale,
                                f16* out_pooled, f16* edge, const unsigned* zscratch, bool fill_all, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[64] = {};

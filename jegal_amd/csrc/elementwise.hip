@@ -406,6 +406,16 @@ hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int 
     return hipGetLastError();
 }
 
+// out[pixel][c] = v[c]: an image whose every pixel is the same channel vector (the all-constant input of the const chain)
+__global__ void broadcast_channels_kernel(const f16* __restrict__ v, int C, f16* __restrict__ out, long total) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) out[i] = v[i % C];
+}
+hipError_t launch_broadcast_channels(const f16* v, int C, f16* out, long pixels, hipStream_t s) {
+    const long total = pixels * C;
+    hipLaunchKernelGGL(broadcast_channels_kernel, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), dim3(256), 0, s, v, C, out, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s) {
     return hipMemsetAsync(p, 0, n * sizeof(f16), s);
 }

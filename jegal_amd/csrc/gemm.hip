@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     float inv_perc = 0.f;
     if constexpr (CONV) {
         if (a.g.rowskip) {
-            rsk = __builtin_amdgcn_readfirstlane(*a.g.rowskip);
+            rsk = conv_skip_decode(__builtin_amdgcn_readfirstlane(*a.g.rowskip), a.g.rowskip_op);
             rsk = rsk > 0 && rsk < a.g.OH ? rsk : 0;
             if (rsk) {
                 const int nimg = a.M / (a.g.OH * a.g.OW);
@@ -243,16 +243,17 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
         }
     }
-    // ConvGeom::in_rowclamp (conv instances with SPR, which has no other meaning for CONV: launch_glds picks them when the pointer
-    // is set): input rows 0..rcl-1 of every image are never read -- they are copies of row rcl (the producer left them out,
-    // ConvGeom::rowskip) -- the loader reads row rcl in their place.  Its own instances: the compare + select + 64-bit add per
-    // LDS-DMA piece cost the 256x256 conv kernel 5 % (conv4 / conv5: 580 -> 610 us) when it was compiled into all of them.
-    constexpr bool ROWCLAMP = CONV && SPR;
-    int rcl = 0;
-    if constexpr (ROWCLAMP) {
-        if (a.g.in_rowclamp) {
-            rcl = __builtin_amdgcn_readfirstlane(*a.g.in_rowclamp);
-            rcl = rcl > 0 && rcl < a.g.H ? rcl : 0;
+    // ConvGeom::in_rowskip / const_in (conv instances with SPR, which has no other meaning for CONV: launch_glds picks them when
+    // the pointer is set): input rows 0..rin-1 of every image were left out by the producer (ConvGeom::rowskip) because they do
+    // not depend on the position; the loader reads them from the const image of the input instead (same pixel, other base).
+    // Its own instances: the compare + select per LDS-DMA piece cost the 256x256 conv kernel 5 % (conv4 / conv5: 580 -> 610 us)
+    // when it was compiled into all of them.
+    constexpr bool ROWCONST = CONV && SPR;
+    int rin = 0;
+    if constexpr (ROWCONST) {
+        if (a.g.in_rowskip && a.g.const_in) {
+            rin = conv_skip_decode(__builtin_amdgcn_readfirstlane(*a.g.in_rowskip), a.g.in_op);
+            rin = rin > 0 ? rin : 0;
         }
     }
     auto row_full = [&](int m) -> long {
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     // share one register (ih << 16 | iw & 0xffff), and the WI weight-row pointers are two base pointers (even / odd
     // 8-row piece: the swizzled chunk depends on the piece's parity only) plus a wave-uniform multiple of 16 rows.
     const f16* xsrc[XI];
+    const f16* xalt[ROWCONST ? XI : 1];          // the same pixel in the const image of the input (ROWCONST)
     int xpix[XI];
     int tidx = 0, tc0 = 0;
     static_assert(WI % 2 == 0, "weight pieces come in even/odd pairs");
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const int ih = oh * a.g.SH - a.g.PH, iw = ow * a.g.SW - a.g.PW;
                 xpix[i] = (ih << 16) | (iw & 0xffff);
                 xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
+                if constexpr (ROWCONST) xalt[i] = a.g.const_in + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
             } else {
                 xpix[i] = 0;
                 xsrc[i] = a.a_tiled ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) * 1024 + (m & 15) * 16 + (c >> 1) * 256 + (c & 1) * 8
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const int ih = (xpix[i] >> 16) + stkh, iw = (int)(short)(xpix[i] & 0xffff) + stkw;
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
-                if (ROWCLAMP && ok && ih < rcl) src += (long)(rcl - ih) * (a.g.W * a.g.C);
+                if (ROWCONST && ok && ih < rin) src = xalt[i] + stapoff;
             } else {
                 src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }
@@ -907,7 +910,7 @@ static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
     if constexpr (CONV) {
-        if (a.g.in_rowclamp) {               // consumer of a row-skipping producer (conv3): the instances with the clamp in their loader
+        if (a.g.in_rowskip && a.g.const_in) {   // consumer of a row-skipping producer: the instances whose loader can read the const image
             if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, true, 2, 4, 2, true>(a, o, s);
             if constexpr (!W2) {
                 if (o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, true, 8, 2, 4, true>(a, o, s);
