@@ -100,7 +100,7 @@ struct jg_handle {
     Lin c1, c2, c3, c4, c5, fc6, ff0, ff2;
     // const chain: what conv2 / conv3 / conv4 compute from an all-constant pooled image (relu(bias1) everywhere) -- the rows of
     // their outputs that the zero-band skip makes position-independent are read from here (ConvGeom::const_in); 4 copies each
-    f16 *gs_c2C = nullptr, *gs_c3C = nullptr, *gs_c4C = nullptr;
+    f16 *gs_c2C = nullptr, *gs_c3C = nullptr, *gs_c4C = nullptr, *gs_c5C = nullptr;
     float* c1_scale255 = nullptr;
     f16* c1_direct = nullptr;      // conv1 weights, slot-major [49][64][16] for the direct kernel
     float* gs_pe = nullptr;
@@ -539,7 +539,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
             g2.rowskip = w; g2.rowskip_op = 0;
             g3.rowskip = w; g3.rowskip_op = 1; g3.in_rowskip = w; g3.in_op = 0; g3.const_in = h->gs_c2C;
             g4.rowskip = w; g4.rowskip_op = 2; g4.in_rowskip = w; g4.in_op = 1; g4.const_in = h->gs_c3C;
-            g5.in_rowskip = w; g5.in_op = 2; g5.const_in = h->gs_c4C;
+            g5.rowskip = w; g5.rowskip_op = 3; g5.in_rowskip = w; g5.in_op = 2; g5.const_in = h->gs_c4C;
         }
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
@@ -556,39 +556,42 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
     e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
-    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream); }));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream, g5.rowskip, g5.rowskip_op, h->gs_c5C); }));
     e.out16 = conv16; e.out32 = conv_out;
     RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
     return JG_OK;
 }
 
-// Const chain (ConvGeom::rowskip): conv2 / conv3 / conv4 of an all-constant pooled image -- relu(bias1) in every pixel, which is
+// Const chain (ConvGeom::rowskip): conv2 .. conv5 of an all-constant pooled image -- relu(bias1) in every pixel, which is
 // what conv1 + max-pool produce wherever the frames are blanked.  Computed once per weight load with the run-time kernels
 // (same MFMA sequence per output element, so the rows are bit-identical to what the layers would compute per position);
 // 4 copies per layer so that every launch has the 256 rows the LDS-DMA kernel needs.
 int gs_build_const_chain(jg_handle* h) {
-    h->gs_c2C = h->gs_c3C = h->gs_c4C = nullptr;
+    h->gs_c2C = h->gs_c3C = h->gs_c4C = h->gs_c5C = nullptr;
     if (!h->opts.gemm_glds) return JG_OK;
     constexpr int NC = 4;
-    f16 *zc, *poolC, *c2C, *c3C, *c4C;
+    f16 *zc, *poolC, *c2C, *c3C, *c4C, *c5C;
     h->wallocs = &h->wallocs_gs;
     RET(walloc(h, (size_t)64, &zc));
     RET(walloc(h, (size_t)NC * 43 * 78 * 64, &poolC));
     RET(walloc(h, (size_t)NC * 20 * 37 * 128, &c2C));
     RET(walloc(h, (size_t)NC * 10 * 19 * 256, &c3C));
     RET(walloc(h, (size_t)NC * 10 * 10 * 256, &c4C));
+    RET(walloc(h, (size_t)NC * 10 * 10 * 256, &c5C));
     HIPCHK(h, launch_conv1_zconst(h->c1_direct, 1.0f / 255.0f, zc, h->stream));
     HIPCHK(h, launch_broadcast_channels(zc, 64, poolC, (long)NC * 43 * 78, h->stream));
     const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);
     const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);
     const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);
+    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);
     Epi e;
     e.relu = 1;
     e.out16 = c2C; RET(gemm(h, JG_ST_CONV, poolC, 0, NC * 20 * 37, h->c2, e, &g2));
     e.out16 = c3C; RET(gemm(h, JG_ST_CONV, c2C, 0, NC * 10 * 19, h->c3, e, &g3));
     e.out16 = c4C; RET(gemm(h, JG_ST_CONV, c3C, 0, NC * 10 * 10, h->c4, e, &g4));
+    e.out16 = c5C; RET(gemm(h, JG_ST_CONV, c4C, 0, NC * 10 * 10, h->c5, e, &g5));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->gs_c2C = c2C; h->gs_c3C = c3C; h->gs_c4C = c4C;
+    h->gs_c2C = c2C; h->gs_c3C = c3C; h->gs_c4C = c4C; h->gs_c5C = c5C;
     return JG_OK;
 }
 

@@ -36,10 +36,12 @@ struct ConvGeom {
     int in_op;
     const f16* const_in;      // ... and the const image [H][W][C] of the input they are read from instead
 };
-// op 0: conv2 (the word itself); op 1: conv3 (3x3, stride 2, pad 1: rows whose window ends below s2); op 2: conv4 (stride 1, pad 1)
+// op 0: conv2 (the word itself); op 1: conv3 (3x3, stride 2, pad 1: rows whose window ends above s2); op 2: conv4 and op 3: conv5
+// (3x3, vertical stride 1, pad 1: one row fewer each)
 __host__ __device__ inline int conv_skip_decode(int w, int op) {
     const int s3 = w / 2;
-    return op == 0 ? w : op == 1 ? s3 : (s3 > 0 ? s3 - 1 : 0);
+    const int s = op == 0 ? w : s3 - (op - 1);
+    return s > 0 ? s : 0;
 }
 constexpr int CONV1_ZHDR_WORDS = 64;        // header of conv1's zero-scan scratch: 32 words of zconst, then ...
 constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's position-independent leading rows
@@ -155,7 +157,9 @@ hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long position
 hipError_t launch_conv1_zconst(const f16* Wd, float scale, f16* zconst, hipStream_t s);
 size_t conv1_zmask_elems(int nclip, int T);
 size_t conv1_edge_elems(long positions);
-hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s);
+// in_rowskip / in_op / const_in as in ConvGeom: input rows below conv_skip_decode(*in_rowskip, in_op) come from the const image
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* in_rowskip = nullptr,
+                               int in_op = 0, const f16* const_in = nullptr);
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s);
 hipError_t launch_layernorm(const float* in, const float* w, const float* b, int rows, int D, int flavour,

@@ -55,7 +55,9 @@ hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st,
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool (1,3,3)/(1,2,2), no padding, NHWC fp16, 8 channels per thread (gestsync.py:42-45,74-77).
-__global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
+__global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out, int N, int H, int W, int C, int OH, int OW,
+                               const int* __restrict__ in_rowskip, int in_op, const f16* __restrict__ const_in) {
+    const int rin = in_rowskip && const_in ? conv_skip_decode(*in_rowskip, in_op) : 0;
     const int cv = C / 8;
     const long total = (long)N * OH * OW * cv;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -70,7 +72,9 @@ __global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(in + (((long)n * H + oh * 2 + kh) * W + ow * 2 + kw) * C + c8 * 8);
+                const int ih = oh * 2 + kh;
+                const f16* img = ih < rin ? const_in : in + (long)n * H * W * C;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(img + ((long)ih * W + ow * 2 + kw) * C + c8 * 8);
                 if (kh == 0 && kw == 0) m = v;
                 else
 #pragma unroll
@@ -80,11 +84,12 @@ __global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out
     }
 }
 
-hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s) {
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* in_rowskip, int in_op,
+                               const f16* const_in) {
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
     const long total = (long)N * OH * OW * (C / 8);
     const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, N, H, W, C, OH, OW, in_rowskip, in_op, const_in);
     return hipGetLastError();
 }
 
