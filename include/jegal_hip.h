@@ -74,12 +74,21 @@ int jg_sync(jg_handle* h);
  *      "module." prefix already stripped; unknown keys (net_aud.*, lstm.*, ...) are accepted and
  *      ignored, missing hot-path keys make jg_finalize_weights fail (strict). ------------------- */
 int jg_load_tensor(jg_handle* h, const char* name, const void* data_host, const int64_t* shape_host, int ndim, int dtype);
-/* which: 1 = GestSync, 2 = JEGAL, 3 = both.  Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo. */
+/* which: bit 0 = GestSync, bit 1 = JEGAL, bit 2 = XLM-RoBERTa (keys of transformers.XLMRobertaModel under the prefix "xlmr.").
+ * Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo. */
 int jg_finalize_weights(jg_handle* h, int which);
 
 /* Re-run the JG_PREC_FP16_BC calibration on caller-supplied clips (same layout as jg_gestsync_clip; device
  * pointer) instead of the built-in synthetic ones, e.g. a few real videos.  frames == NULL: built-in clips. */
 int jg_calibrate_gesture(jg_handle* h, const void* frames, int frames_dtype, int B, int T);
+
+/* ---- XLM-RoBERTa text front end ------------------------------------------------
+ * Replaces `mroberta(input_ids, attention_mask=text_mask).last_hidden_state` of JEGAL.get_roberta_embeddings
+ * (models/jegal.py:116-129; the reference runs transformers.XLMRobertaModel "xlm-roberta-base" on the CPU).  The tokenizer stays
+ * on the host.  input_ids, attention_mask: (B, L) int32 on the device (attention_mask NULL = all ones); out (B, L, 768) fp32.
+ * Third-party arithmetic: parity is pinned against transformers.XLMRobertaModel with seeded random weights
+ * (tests/golden/xlmr.npz), not against the released checkpoint, which is not available offline. */
+int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L, float* out);
 
 /* ---- GestSync (models/gestsync.py) ---------------------------------------------------------- */
 /* Per-clip features: frames (B,T,270,480,3) u8 (JG_U8, the /255 of inference_embs.py:282 is applied

@@ -4,7 +4,7 @@ Public surface mirrors the reference's hot-path interface: ``GestSync`` (models/
 ``JEGAL`` (models/jegal.py), metric functions (evaluation/evaluate_*.py).  Nothing here falls back
 to PyTorch math: without libjegal_hip.so and a HIP device the engine raises.
 """
-__all__ = ["GestSync", "JEGAL", "Engine"]
+__all__ = ["GestSync", "JEGAL", "XLMRoberta", "Engine"]
 
 
 def __getattr__(name):
@@ -14,6 +14,9 @@ def __getattr__(name):
     if name == "JEGAL":
         from .jegal import JEGAL
         return JEGAL
+    if name == "XLMRoberta":
+        from .xlmr import XLMRoberta
+        return XLMRoberta
     if name == "Engine":
         from ._lib import Engine
         return Engine

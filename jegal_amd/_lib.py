@@ -41,6 +41,7 @@ _SIGS = {
     "jg_logmel": [_P, _P, _I, _I, _P, _P],
     "jg_mask_resize": [_P, _P, _I, _I, _I, _P, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
+    "jg_xlmr_encode": [_P, _P, _P, _I, _I, _P],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
     "jg_fuse_content": [_P, _P, _I, _P],
     "jg_l2norm": [_P, _P, _P, _I, _I],
@@ -171,6 +172,8 @@ class Engine:
         return torch.as_tensor(t, device=self.device).to(torch.float32).contiguous()
 
     def _i32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int32).contiguous()
         return torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.int32)), device=self.device)
 
     def sync(self):
@@ -323,6 +326,22 @@ class Engine:
         m = None if mask is None else self._f32(mask).reshape(B, L)
         out = torch.empty((B, L, 256), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_jegal_text(self.h, _ptr(states), _ptr(m), B, L, _ptr(out)))
+        return out
+
+    def xlmr_encode(self, input_ids, attention_mask=None):
+        """XLM-RoBERTa last_hidden_state: input_ids / attention_mask (B,L) int -> (B,L,768) fp32 (jg_xlmr_encode)."""
+        self._bind_stream()
+        ids = self._i32(input_ids)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be (B, L)")
+        B, L = ids.shape
+        m = None
+        if attention_mask is not None:
+            m = self._i32(attention_mask)
+            if tuple(m.shape) != (B, L):
+                raise ValueError("attention_mask must have the shape of input_ids")
+        out = torch.empty((B, L, 768), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.jg_xlmr_encode(self.h, _ptr(ids), _ptr(m), B, L, _ptr(out)))
         return out
 
     def word_pool(self, seq, segments, dst, dst_col):

@@ -111,6 +111,13 @@ struct jg_handle {
     LNp ip_ln, rgb_norm, text_norm;
     float* rgb_pe = nullptr;
     EncLayer rgb_layers[6], text_layers[3];
+    // XLM-RoBERTa text front end (third-party transformers.XLMRobertaModel, call site jegal.py:116-129)
+    bool xl_ready = false;
+    int xl_layers_n = 0, xl_vocab = 0, xl_maxpos = 0;
+    float *xl_word = nullptr, *xl_pos = nullptr, *xl_type = nullptr;
+    LNp xl_emb_ln;
+    std::vector<EncLayer> xl_layers;
+    std::vector<void*> wallocs_xl;
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
     size_t feats_cap = 0;
@@ -933,6 +940,99 @@ int jegal_text_impl(jg_handle* h, const float* states, const float* mask, int B,
     return gemm(h, JG_ST_GEMM, n16, 768, M, h->op_text, o);
 }
 
+// ------------------------------------------------------------------------------------ XLM-RoBERTa (text front end)
+// State-dict keys: those of transformers.XLMRobertaModel (add_pooling_layer irrelevant) under the prefix "xlmr.":
+// xlmr.embeddings.{word,position,token_type}_embeddings.weight, xlmr.embeddings.LayerNorm.{weight,bias},
+// xlmr.encoder.layer.<i>.attention.self.{query,key,value}.{weight,bias}, .attention.output.{dense,LayerNorm}.*,
+// .intermediate.dense.*, .output.{dense,LayerNorm}.*.  The number of layers is the number present; hidden size 768,
+// 12 heads of 64, intermediate 3072 (xlm-roberta-base); the vocabulary and position table sizes come from the tensors.
+int finalize_xlmr(jg_handle* h) {
+    h->xl_ready = false;
+    (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->wallocs_xl) (void)hipFree(p);
+    h->wallocs_xl.clear();
+    h->xl_layers.clear();
+    h->wallocs = &h->wallocs_xl;
+    h->cur_model = 3;
+    constexpr int D = 768, DFF = 3072;
+    const HostTensor* t = find(h, "xlmr.embeddings.word_embeddings.weight");
+    if (!t || t->numel() % D) JG_FAIL(h, JG_ERR_WEIGHT, "missing or malformed 'xlmr.embeddings.word_embeddings.weight'");
+    h->xl_vocab = (int)(t->numel() / D);
+    RET(upload(h, t->v, &h->xl_word));
+    t = find(h, "xlmr.embeddings.position_embeddings.weight");
+    if (!t || t->numel() % D) JG_FAIL(h, JG_ERR_WEIGHT, "missing or malformed 'xlmr.embeddings.position_embeddings.weight'");
+    h->xl_maxpos = (int)(t->numel() / D);
+    RET(upload(h, t->v, &h->xl_pos));
+    RET(need(h, "xlmr.embeddings.token_type_embeddings.weight", D, &t));
+    RET(upload(h, t->v, &h->xl_type));
+    RET(make_ln(h, "xlmr.embeddings.LayerNorm.weight", "xlmr.embeddings.LayerNorm.bias", D, &h->xl_emb_ln));
+    int nl = 0;
+    while (find(h, "xlmr.encoder.layer." + std::to_string(nl) + ".attention.self.query.weight")) ++nl;
+    if (nl == 0) JG_FAIL(h, JG_ERR_WEIGHT, "no 'xlmr.encoder.layer.*' weights");
+    h->xl_layers.resize(nl);
+    for (int l = 0; l < nl; ++l) {
+        const std::string p = "xlmr.encoder.layer." + std::to_string(l);
+        EncLayer* L = &h->xl_layers[l];
+        std::vector<float> w((size_t)3 * D * D), b((size_t)3 * D);
+        const char* names[3] = {"query", "key", "value"};
+        for (int i = 0; i < 3; ++i) {
+            const HostTensor *wi, *bi;
+            RET(need(h, p + ".attention.self." + names[i] + ".weight", (int64_t)D * D, &wi));
+            RET(need(h, p + ".attention.self." + names[i] + ".bias", D, &bi));
+            std::memcpy(&w[(size_t)i * D * D], wi->v.data(), sizeof(float) * D * D);
+            std::memcpy(&b[(size_t)i * D], bi->v.data(), sizeof(float) * D);
+        }
+        RET(pack_matrix(h, w, b, 3 * D, D, LK_CONTENT, &L->qkv));
+        RET(make_linear(h, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, &L->out, LK_CONTENT));
+        RET(make_ln(h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", D, &L->n1));
+        RET(make_linear(h, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", DFF, D, &L->ff1, LK_CONTENT));
+        RET(make_linear(h, p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, &L->ff2, LK_CONTENT));
+        RET(make_ln(h, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", D, &L->n2));
+    }
+    h->xl_layers_n = nl;
+    h->xl_ready = true;
+    return JG_OK;
+}
+
+// XLMRobertaModel.forward(input_ids, attention_mask).last_hidden_state: post-norm BERT layers (LayerNorm eps 1e-5, exact GELU),
+// the key padding mask of attention_mask, position ids from the non-pad tokens (padding_idx = 1).
+int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
+    if (!h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "XLM-RoBERTa weights not finalized (jg_finalize_weights(h, 4))");
+    if (B <= 0 || L <= 0 || L > h->xl_maxpos - 2) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < L <= %d", h->xl_maxpos - 2);
+    constexpr int D = 768, DFF = 3072, H = 12;
+    const int M = B * L;
+    float *x32, *t32, *mk = nullptr;
+    f16 *x16, *qkv, *att, *hid;
+    RET(wsalloc(h, (size_t)M * D, &x32));
+    RET(wsalloc(h, (size_t)M * D, &x16));
+    RET(wsalloc(h, (size_t)M * DFF, &t32));
+    RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
+    RET(wsalloc(h, (size_t)M * D, &att));
+    RET(wsalloc(h, (size_t)M * DFF, &hid));
+    if (amask) {
+        RET(wsalloc(h, (size_t)M, &mk));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_mask_i32_f32(amask, mk, M, h->stream); }));
+    }
+    RET(timed(h, JG_ST_MISC, [&] { return launch_xlmr_embed(ids, B, L, D, 1, h->xl_vocab, h->xl_maxpos, h->xl_word, h->xl_pos, h->xl_type, t32, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->xl_emb_ln.w, h->xl_emb_ln.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
+    for (int l = 0; l < h->xl_layers_n; ++l) {
+        const EncLayer& Ly = h->xl_layers[l];
+        const bool last = l + 1 == h->xl_layers_n;
+        Epi e; e.out16 = qkv;
+        RET(gemm(h, JG_ST_GEMM, x16, D, M, Ly.qkv, e));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mk, B, L, H, 64, att, h->opts, h->stream); }));
+        Epi r; r.res = x32; r.ldr = D; r.out32 = t32;
+        RET(gemm(h, JG_ST_GEMM, att, D, M, Ly.out, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n1.w, Ly.n1.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
+        Epi f; f.out32 = t32;
+        RET(gemm(h, JG_ST_GEMM, x16, D, M, Ly.ff1, f));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_gelu(t32, hid, (long)M * DFF, h->stream); }));
+        RET(gemm(h, JG_ST_GEMM, hid, DFF, M, Ly.ff2, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n2.w, Ly.n2.b, M, D, LN_STD, 0, last ? out : x32, x16, h->stream); }));
+    }
+    return JG_OK;
+}
+
 int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (rows <= 0) JG_FAIL(h, JG_ERR_ARG, "rows must be positive");
@@ -988,6 +1088,7 @@ int jg_destroy(jg_handle* h) {
         for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
         for (void* p : h->wallocs_gs) hipFree(p);
         for (void* p : h->wallocs_jg) hipFree(p);
+        for (void* p : h->wallocs_xl) hipFree(p);
         if (h->feats) hipFree(h->feats);
         if (h->gs_qpe) hipFree(h->gs_qpe);
         h->ws.release();
@@ -1090,6 +1191,7 @@ int jg_finalize_weights(jg_handle* h, int which) {
     h->gs_qpe_valid = false;
     if (which & 1) { RET(finalize_gestsync(h)); RET(gs_build_const_chain(h)); }
     if (which & 2) RET(finalize_jegal(h));
+    if (which & 4) RET(finalize_xlmr(h));
     // the fp32 host copies of the checkpoint (incl. the unused audio/LSTM tensors of gestsync.py:23-32) are no longer
     // needed: packed device weights + the w32/b32 of the bias-corrected layers carry everything
     h->host.clear();
@@ -1219,6 +1321,13 @@ int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, i
     if (!states || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
     return jegal_text_impl(h, states, mask, B, L, out);
+}
+
+int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L, float* out) {
+    ENTER(h);
+    if (!input_ids || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return xlmr_encode_impl(h, input_ids, attention_mask, B, L, out);
 }
 
 int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {

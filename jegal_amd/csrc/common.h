@@ -182,6 +182,10 @@ hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, h
 hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
+hipError_t launch_xlmr_embed(const int32_t* ids, int B, int L, int D, int pad_id, int vocab, int maxpos, const float* word, const float* pos,
+                             const float* type, float* out, hipStream_t s);
+hipError_t launch_gelu(const float* in, f16* out, long n, hipStream_t s);
+hipError_t launch_mask_i32_f32(const int32_t* in, float* out, long n, hipStream_t s);
 hipError_t launch_broadcast_channels(const f16* v, int C, f16* out, long pixels, hipStream_t s);
 hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s);
 hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s);

@@ -411,6 +411,63 @@ hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// XLM-RoBERTa front end (third-party transformers.XLMRobertaModel, call site jegal.py:116-129).
+// Embeddings: word[id] + position[pid] + token_type[0], pid = padding_idx + (number of non-pad tokens up to and including
+// this one) for non-pad tokens and padding_idx for pads (create_position_ids_from_input_ids).  One wave per token row.
+__global__ __launch_bounds__(256) void xlmr_embed_kernel(const int32_t* __restrict__ ids, int B, int L, int D, int pad_id, int vocab, int maxpos,
+                                                         const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type,
+                                                         float* __restrict__ out) {
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (long)B * L) return;
+    const int b = (int)(row / L), t = (int)(row - (long)b * L);
+    int cnt = 0;
+    for (int j = lane; j <= t; j += 64) cnt += ids[(long)b * L + j] != pad_id ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    int id = ids[row];
+    int pid = id != pad_id ? pad_id + cnt : pad_id;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    pid = pid >= maxpos ? maxpos - 1 : pid;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(word + (long)id * D + c);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long)pid * D + c);
+        const f32x4 ty = *reinterpret_cast<const f32x4*>(type + c);
+        *reinterpret_cast<f32x4*>(out + row * D + c) = (w + ty) + p;       // HF: inputs_embeds + token_type_embeddings, then + position
+    }
+}
+hipError_t launch_xlmr_embed(const int32_t* ids, int B, int L, int D, int pad_id, int vocab, int maxpos, const float* word, const float* pos,
+                             const float* type, float* out, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(xlmr_embed_kernel, dim3((unsigned)(((long)B * L + 3) / 4)), dim3(256), 0, s, ids, B, L, D, pad_id, vocab, maxpos, word, pos, type, out);
+    return hipGetLastError();
+}
+// exact GELU (erf form, the HF "gelu"): fp32 in -> fp16 out
+__global__ void gelu_kernel(const float* __restrict__ in, f16* __restrict__ out, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + i * 4);
+        auto g = [](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); };
+        const f16x4 h = {(f16)g(v.x), (f16)g(v.y), (f16)g(v.z), (f16)g(v.w)};
+        *reinterpret_cast<f16x4*>(out + i * 4) = h;
+    }
+}
+hipError_t launch_gelu(const float* in, f16* out, long n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536)), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+// int attention mask (1 = token, 0 = padding) -> the float key mask the attention kernels take
+__global__ void mask_i32_f32_kernel(const int32_t* __restrict__ in, float* __restrict__ out, long n) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] != 0 ? 1.f : 0.f;
+}
+hipError_t launch_mask_i32_f32(const int32_t* in, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(mask_i32_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    return hipGetLastError();
+}
+
 // out[pixel][c] = v[c]: an image whose every pixel is the same channel vector (the all-constant input of the const chain)
 __global__ void broadcast_channels_kernel(const f16* __restrict__ v, int C, f16* __restrict__ out, long total) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) out[i] = v[i % C];

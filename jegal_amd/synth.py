@@ -134,6 +134,46 @@ def jegal_state_dict(seed=JEGAL_SEED):
     return g.sd
 
 
+XLMR_SEED = 4242
+
+
+def xlmr_state_dict(seed=XLMR_SEED, vocab=1000, layers=4, max_pos=514):
+    """Keys and shapes of ``transformers.XLMRobertaModel(...).state_dict()`` for the xlm-roberta-base architecture (hidden 768,
+    12 heads, intermediate 3072, type vocabulary 1) with a reduced vocabulary / depth: seeded random stand-ins for the released
+    checkpoint, which is not available offline (jegal.py:13-14).  Weight scales keep the activations O(1) through the layers."""
+    g = _Gen(seed)
+    D, DFF = 768, 3072
+    g.sd["embeddings.word_embeddings.weight"] = (g.rng.standard_normal((vocab, D)) * 0.5).astype(np.float32)
+    g.sd["embeddings.position_embeddings.weight"] = (g.rng.standard_normal((max_pos, D)) * 0.3).astype(np.float32)
+    g.sd["embeddings.token_type_embeddings.weight"] = (g.rng.standard_normal((1, D)) * 0.1).astype(np.float32)
+    g.ln("embeddings.LayerNorm", D)
+    for l in range(layers):
+        p = f"encoder.layer.{l}"
+        for nm in ("query", "key", "value"):
+            g.linear(f"{p}.attention.self.{nm}", D, D)
+        g.linear(f"{p}.attention.output.dense", D, D)
+        g.ln(f"{p}.attention.output.LayerNorm", D)
+        g.linear(f"{p}.intermediate.dense", DFF, D, relu_after=True)
+        g.linear(f"{p}.output.dense", D, DFF)
+        g.ln(f"{p}.output.LayerNorm", D)
+    return g.sd
+
+
+def xlmr_inputs(seed, batch, length, vocab=1000):
+    """(input_ids, attention_mask) int32 (B, L) in the tokenizer's convention: <s> = 0 first, </s> = 2 last, <pad> = 1 behind it;
+    sample 0 has no padding, the others are shorter."""
+    rng = np.random.default_rng(seed)
+    ids = np.full((batch, length), 1, dtype=np.int32)
+    mask = np.zeros((batch, length), dtype=np.int32)
+    for b in range(batch):
+        n = length if b == 0 else int(rng.integers(max(3, length // 3), length + 1))
+        ids[b, 0] = 0
+        ids[b, 1:n - 1] = rng.integers(3, vocab, n - 2)
+        ids[b, n - 1] = 2
+        mask[b, :n] = 1
+    return ids, mask
+
+
 # --------------------------------------------------------------------------- inputs
 
 def synth_frames(seed, n_clips, n_frames, height=270, width=480, mask_rows=110):

@@ -1,0 +1,59 @@
+"""XLM-RoBERTa text front end on the MI355X engine.
+
+The reference keeps ``tokenizer = AutoTokenizer.from_pretrained("xlm-roberta-base")`` and
+``mroberta = XLMRobertaModel.from_pretrained("xlm-roberta-base")`` as module globals (models/jegal.py:13-14) and runs the model
+on the CPU inside ``JEGAL.get_roberta_embeddings`` (:116-129).  ``XLMRoberta`` replaces ``mroberta``: same call, same
+``last_hidden_state``, computed by libjegal_hip (post-norm BERT layers on the LDS-DMA GEMM + MFMA attention kernels).  The
+tokenizer (sentencepiece, host side) is not part of this package; ``roberta_embeddings`` reproduces the 5-tuple of
+``get_roberta_embeddings`` from any tokenizer with the HuggingFace calling convention.
+"""
+import torch
+
+from ._lib import Engine
+
+
+class _Output:
+    def __init__(self, last_hidden_state):
+        self.last_hidden_state = last_hidden_state
+
+
+class XLMRoberta:
+    """Drop-in for the ``mroberta`` global of models/jegal.py: ``XLMRoberta()(input_ids, attention_mask=mask).last_hidden_state``."""
+
+    def __init__(self, engine=None, device=None):
+        self.engine = engine if engine is not None else Engine.get(device)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """``state_dict``: that of ``transformers.XLMRobertaModel`` (keys with or without a leading ``roberta.``); the pooler
+        and the registered index buffers are ignored."""
+        sd = {}
+        for k, v in state_dict.items():
+            if k.startswith("roberta."):
+                k = k[len("roberta."):]
+            if k.startswith("pooler.") or k.endswith("position_ids") or k.endswith("token_type_ids"):
+                continue
+            sd["xlmr." + k] = v
+        self.engine.load_tensors(sd)
+        self.engine.finalize(4)
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def __call__(self, input_ids, attention_mask=None):
+        return _Output(self.engine.xlmr_encode(input_ids, attention_mask))
+
+
+def roberta_embeddings(model, tokenizer, text):
+    """``JEGAL.get_roberta_embeddings`` (models/jegal.py:116-129) with ``model`` in place of the CPU ``mroberta``."""
+    with torch.no_grad():
+        text_batch = [words.split(" ") for words in text]
+        text_input = tokenizer(text_batch, return_tensors="pt", padding=True, is_split_into_words=True, return_offsets_mapping=True)
+        input_ids = text_input["input_ids"]
+        text_mask = text_input["attention_mask"]
+        offset_mapping = text_input["offset_mapping"]
+        text_emb = model(input_ids, attention_mask=text_mask).last_hidden_state
+    return text_emb, text_mask, text_batch, input_ids, offset_mapping

@@ -487,3 +487,41 @@ def mask_resize_frames(frames_u8, mask_y, width=480, height=270):
             r = cv_resize_linear_u8(img, width, height)
         out[i] = r
     return out
+
+
+# --------------------------------------------------------------------------- XLM-RoBERTa
+def xlmr_forward(sd, input_ids, attention_mask=None, pad_id=1, heads=12, eps=1e-5):
+    """``XLMRobertaModel(input_ids, attention_mask=mask).last_hidden_state`` (call site jegal.py:116-129) restated:
+    third-party arithmetic (transformers' modeling_xlm_roberta.py: RobertaEmbeddings + 12 post-norm BERT layers, exact GELU).
+    ``sd``: the model's state_dict (keys without prefix).  Pinned against transformers itself in tests/golden/xlmr.npz."""
+    ids = torch.as_tensor(input_ids).long()
+    B, L = ids.shape
+    nonpad = (ids != pad_id).long()
+    pos_ids = torch.cumsum(nonpad, dim=1) * nonpad + pad_id                      # create_position_ids_from_input_ids
+    g = lambda k: torch.as_tensor(sd[k]).float()
+    x = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.token_type_embeddings.weight")[0] + \
+        g("embeddings.position_embeddings.weight")[pos_ids]
+    x = F.layer_norm(x, (x.shape[-1],), g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    D = x.shape[-1]
+    dk = D // heads
+    bias = None
+    if attention_mask is not None:
+        m = torch.as_tensor(attention_mask).float()
+        bias = (1.0 - m)[:, None, None, :] * torch.finfo(torch.float32).min
+    l = 0
+    while f"encoder.layer.{l}.attention.self.query.weight" in sd:
+        p = f"encoder.layer.{l}"
+        lin = lambda name, t: F.linear(t, g(f"{p}.{name}.weight"), g(f"{p}.{name}.bias"))
+        q = lin("attention.self.query", x).view(B, L, heads, dk).transpose(1, 2)
+        k = lin("attention.self.key", x).view(B, L, heads, dk).transpose(1, 2)
+        v = lin("attention.self.value", x).view(B, L, heads, dk).transpose(1, 2)
+        sc = q @ k.transpose(-1, -2) / math.sqrt(dk)
+        if bias is not None:
+            sc = sc + bias
+        ctx = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, L, D)
+        x = F.layer_norm(x + lin("attention.output.dense", ctx), (D,), g(f"{p}.attention.output.LayerNorm.weight"),
+                         g(f"{p}.attention.output.LayerNorm.bias"), eps)
+        h = F.gelu(lin("intermediate.dense", x))
+        x = F.layer_norm(x + lin("output.dense", h), (D,), g(f"{p}.output.LayerNorm.weight"), g(f"{p}.output.LayerNorm.bias"), eps)
+        l += 1
+    return x

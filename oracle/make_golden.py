@@ -111,9 +111,41 @@ def golden_asd(ea):
     print("asd golden: correct", counts, "of", n)
 
 
+def golden_xlmr():
+    """(vii) XLM-RoBERTa text front end: the third-party model itself -- transformers.XLMRobertaModel with the
+    xlm-roberta-base architecture (reduced vocabulary / depth, the released checkpoint is not available offline), strict-loaded
+    with the seeded weights of synth.xlmr_state_dict -- run as the reference's call site does (jegal.py:126-127)."""
+    import transformers
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+    sd = synth.xlmr_state_dict()
+    layers = 0
+    while f"encoder.layer.{layers}.attention.self.query.weight" in sd:
+        layers += 1
+    cfg = XLMRobertaConfig(vocab_size=sd["embeddings.word_embeddings.weight"].shape[0], hidden_size=768, num_hidden_layers=layers,
+                           num_attention_heads=12, intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1,
+                           pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5, hidden_act="gelu",
+                           hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    missing = [k for k in missing if "position_ids" not in k and "token_type_ids" not in k]      # registered buffers, not weights
+    assert not missing and not unexpected, (missing, unexpected)
+    ids, mask = synth.xlmr_inputs(9011, 3, 24)
+    with torch.no_grad():
+        out = model(torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long()).last_hidden_state
+        out_nomask = model(torch.from_numpy(ids[:1]).long()).last_hidden_state
+    np.savez_compressed(os.path.join(OUT, "xlmr.npz"), seed=9011, input_ids=ids, attention_mask=mask, last_hidden_state=out.numpy(),
+                        last_hidden_state_nomask=out_nomask.numpy(), transformers_version=transformers.__version__)
+    print("xlmr golden:", out.shape, "transformers", transformers.__version__)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "asd":           # regenerate only tests/golden/asd.npz
         golden_asd(_import_eval("evaluate_asd"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "xlmr":          # regenerate only tests/golden/xlmr.npz
+        os.makedirs(OUT, exist_ok=True)
+        torch.manual_seed(0)
+        golden_xlmr()
         return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)

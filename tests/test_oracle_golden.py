@@ -153,3 +153,15 @@ def test_cv_resize_restatement_properties():
     assert np.abs(O.cv_resize_linear_u8(big).astype(np.float32) - box).max() <= 0.5
     out = O.mask_resize_frames(rng.integers(0, 256, (2, 300, 500, 3), dtype=np.uint8), [-1, 100])
     assert out.shape == (2, 270, 480, 3) and out[0, :111].max() == 0 and out[0, 111].max() > 0 and out[1, :80].max() == 0
+
+
+def test_xlmr_oracle_matches_transformers(golden_dir):
+    """the XLM-RoBERTa restatement against transformers.XLMRobertaModel itself (seeded weights of
+    synth.xlmr_state_dict strict-loaded into the third-party model by oracle/make_golden.py xlmr)."""
+    g = np.load(os.path.join(golden_dir, "xlmr.npz"))
+    sd = synth.xlmr_state_dict()
+    with torch.no_grad():
+        out = O.xlmr_forward(sd, g["input_ids"], g["attention_mask"]).numpy()
+        out1 = O.xlmr_forward(sd, g["input_ids"][:1]).numpy()
+    assert np.abs(out - g["last_hidden_state"]).max() < 2e-5
+    assert np.abs(out1 - g["last_hidden_state_nomask"]).max() < 2e-5
