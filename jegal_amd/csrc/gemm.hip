@@ -205,6 +205,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MI = 16-row MFMA tiles per wave along m (4: 64x64 wave tile, 8: 128x64); WM x WN waves.
 //   <4,4,2>: 256x128 block tile (hi+lo weights fit two LDS stages);  <8,2,4>: 256x256 block tile for single-fp16
 //   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
+// LNF: row-wide 128x512 tile with the residual add and the LayerNorm in the epilogue (tiled fp16 + 8-bit token stream).
+// SPR: plain GEMM -- the next k-tile's DMA pieces are spread over the MFMA schedule (K <= 1024 instances);
+//      CONV -- the loader can read the producer's left-out leading rows from a const image (ConvGeom::in_rowskip / const_in).
+// Every CONV instance honours ConvGeom::rowskip on its output side (compacted row index, row_full()).
 template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
