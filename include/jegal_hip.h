@@ -60,7 +60,7 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
  *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
  *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_parity.py flips every one of them)
- *   "dual_stream"     1: jg_extract_gesture splits a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and runs the two parts concurrently on two internal
+ *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and run the two parts concurrently on two internal
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a

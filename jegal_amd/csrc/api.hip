@@ -1050,6 +1050,36 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     return gemm(h, JG_ST_GEMM, a16, 512, rows, h->al_c2, o);
 }
 
+// Run a batch of B clips as two parts on the two lane streams (option "dual_stream", jg_handle::lane_*): run_part(b0, nb) enqueues
+// one part on h->stream / h->ws, which are the current lane's while it is called.  Entry: both lane streams wait for the caller's
+// stream; exit: the caller's stream waits for both lanes.  Small batches run as one part on the caller's stream.
+template <class F>
+int run_in_lanes(jg_handle* h, int B, int T, F&& run_part) {
+    // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
+    // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
+    if (!h->dual_stream || h->calib || B < 8 || (long)((B * h->dual_split + 4) / 8) * T < 256) return run_part(0, B);
+    for (int l = 0; l < 2; ++l)
+        if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    for (int e = 0; e < 3; ++e)
+        if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
+    hipStream_t user = h->stream;
+    HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
+    const int B0 = (B * h->dual_split + 4) / 8;
+    int rc = JG_OK;
+    for (int l = 0; l < 2 && rc == JG_OK; ++l) {
+        if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
+        h->stream = h->lane_stream[l];
+        std::swap(h->ws, h->lane_ws[l]);
+        rc = l == 0 ? run_part(0, B0) : run_part(B0, B - B0);
+        std::swap(h->ws, h->lane_ws[l]);
+        h->stream = user;
+        if (rc == JG_OK && (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess ||
+                            hipStreamWaitEvent(user, h->lane_ev[1 + l], 0) != hipSuccess)) rc = JG_ERR_HIP;
+    }
+    if (rc == JG_ERR_HIP && h->err.empty()) h->err = "lane stream / event call failed";
+    return rc;
+}
+
 }  // namespace
 
 // ======================================================================================= C ABI
@@ -1209,7 +1239,12 @@ int jg_calibrate_gesture(jg_handle* h, const void* frames, int dtype, int B, int
 int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, float* out) {
     ENTER(h);
     if (!frames || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
-    return gestsync_clip_impl(h, frames, dtype, B, T, out);
+    if (B <= 0 || T <= 0 || (dtype != JG_U8 && dtype != JG_F32)) return gestsync_clip_impl(h, frames, dtype, B, T, out);      // reports the error
+    const size_t esz = dtype == JG_U8 ? 1 : 4;
+    return run_in_lanes(h, B, T, [&](int b0, int nb) -> int {
+        return gestsync_clip_impl(h, reinterpret_cast<const char*>(frames) + (size_t)b0 * T * FH * FW * 3 * esz, dtype, nb, T,
+                                  out + (size_t)b0 * T * 1024);
+    });
 }
 
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16) {
@@ -1373,31 +1408,7 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(jegal_gestures_impl(h, feats, nullptr, nb, T, 1, emb));
         return timed(h, JG_ST_MISC, [&] { return launch_l2norm(emb, emb, nb * T, 512, h->stream); });
     };
-    // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
-    // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
-    if (!h->dual_stream || B < 8 || (long)((B * h->dual_split + 4) / 8) * T < 256) return run_part(0, B);
-    // ---- two lanes.  Entry: both lane streams wait for the caller's stream (the frames); exit: the caller's stream waits for
-    // both lanes (the embeddings).  h->stream / h->ws are the current lane's while its launches are enqueued.
-    for (int l = 0; l < 2; ++l)
-        if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
-    for (int e = 0; e < 3; ++e)
-        if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
-    hipStream_t user = h->stream;
-    HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
-    const int B0 = (B * h->dual_split + 4) / 8;
-    int rc = JG_OK;
-    for (int l = 0; l < 2 && rc == JG_OK; ++l) {
-        if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
-        h->stream = h->lane_stream[l];
-        std::swap(h->ws, h->lane_ws[l]);
-        rc = l == 0 ? run_part(0, B0) : run_part(B0, B - B0);
-        std::swap(h->ws, h->lane_ws[l]);
-        h->stream = user;
-        if (rc == JG_OK && (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess ||
-                            hipStreamWaitEvent(user, h->lane_ev[1 + l], 0) != hipSuccess)) rc = JG_ERR_HIP;
-    }
-    if (rc == JG_ERR_HIP && h->err.empty()) h->err = "lane stream / event call failed";
-    return rc;
+    return run_in_lanes(h, B, T, run_part);
 }
 
 int jg_pool_mean(jg_handle* h, const float* x, const int32_t* off, int n, int D, float* out) {

@@ -236,6 +236,12 @@ def test_dual_stream_lanes_are_bit_identical_and_stream_ordered(engine, models):
     finally:
         engine.set_option("ws_poison", 0)
     assert torch.equal(out, ref)
+    feats = engine.gestsync_clip(frames).clone()                # jg_gestsync_clip runs in lanes as well
+    engine.set_option("dual_stream", 0)
+    try:
+        assert torch.equal(engine.gestsync_clip(frames), feats)
+    finally:
+        engine.set_option("dual_stream", 1)
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     pinned = torch.from_numpy(host).pin_memory()
