@@ -71,3 +71,53 @@ def test_xlmr_properties_and_errors(xlmr):
         xlmr(ids, attention_mask=mask[:, :10])
     with pytest.raises(RuntimeError):
         xlmr(np.ones((1, 600), np.int32))                             # beyond the position table
+
+
+class StubTokenizer:
+    """HuggingFace-fast-tokenizer calling convention (is_split_into_words, offsets, padding) over a toy vocabulary: every word
+    becomes one or two sub-word ids; <s> = 0, </s> = 2, <pad> = 1 as in xlm-roberta (the real sentencepiece model is not
+    available offline)."""
+
+    def __call__(self, text_batch, return_tensors="pt", padding=True, is_split_into_words=True, return_offsets_mapping=True):
+        rows = []
+        for words in text_batch:
+            ids, offs = [0], [(0, 0)]
+            for w in words:
+                h = sum(ord(c) * (i + 7) for i, c in enumerate(w))
+                pieces = 1 + (len(w) > 4)
+                cut = len(w) // 2 if pieces == 2 else len(w)
+                ids.append(3 + h % 900); offs.append((0, cut))
+                if pieces == 2:
+                    ids.append(3 + (h * 31 + 5) % 900); offs.append((cut, len(w)))
+            ids.append(2); offs.append((0, 0))
+            rows.append((ids, offs))
+        L = max(len(r[0]) for r in rows)
+        input_ids = torch.ones(len(rows), L, dtype=torch.long)
+        mask = torch.zeros(len(rows), L, dtype=torch.long)
+        offsets = torch.zeros(len(rows), L, 2, dtype=torch.long)
+        for b, (ids, offs) in enumerate(rows):
+            input_ids[b, :len(ids)] = torch.tensor(ids)
+            mask[b, :len(ids)] = 1
+            offsets[b, :len(ids)] = torch.tensor(offs)
+        return {"input_ids": input_ids, "attention_mask": mask, "offset_mapping": offsets}
+
+
+def test_text_to_content_embedding_end_to_end(xlmr):
+    """jegal.py:116-129 + 377-420 with the engine in place of the CPU mroberta: sentences -> tokenizer (host) -> XLM-RoBERTa (engine)
+    -> JEGAL text encoder + word pooling + fusion/align (engine) -> word-level content embeddings; against the same JEGAL path fed
+    with the fp32 restatement's hidden states."""
+    from jegal_amd.jegal import JEGAL
+    from jegal_amd.xlmr import roberta_embeddings
+    text = ["so we went over there yesterday", "and then it suddenly stopped working", "hello"]
+    tok = StubTokenizer()
+    jg = JEGAL(engine=xlmr.engine, text_encoder=lambda t: roberta_embeddings(xlmr, tok, t))
+    jg.load_state_dict(synth.jegal_state_dict())
+    c = jg.forward_inference(text=text)
+    pack = roberta_embeddings(xlmr, tok, text)
+    with torch.no_grad():
+        states = O.xlmr_forward(synth.xlmr_state_dict(), pack[3].numpy(), pack[1].numpy())
+    c_ref = jg.forward_inference(text=(states, pack[1], pack[2], pack[3], pack[4]))
+    assert c.shape == c_ref.shape and c.shape[0] == 3 and c.shape[2] == 512
+    e = rel(c.cpu(), c_ref.cpu())
+    print("content embeddings, engine XLM-R vs oracle XLM-R hidden states: rel-L2 %.3e" % e)
+    assert e < TOL
