@@ -1070,7 +1070,9 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part) {
         if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
         h->stream = h->lane_stream[l];
         std::swap(h->ws, h->lane_ws[l]);
+        h->opts.lanes_active = true;
         rc = l == 0 ? run_part(0, B0) : run_part(B0, B - B0);
+        h->opts.lanes_active = false;
         std::swap(h->ws, h->lane_ws[l]);
         h->stream = user;
         if (rc == JG_OK && (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess ||

@@ -132,6 +132,8 @@ struct EngineOpts {
     bool gemm_big_tile = true, gemm_small_tile = true, gemm_tall_tile = true;
     int gemm_counted = 1;                // counted s_waitcnt between a tile's epilogue stores and the next tile's first DMA
     int gemm_stagger = 0;                // 10-ns ticks per phase (0: default policy, -1: off)
+    bool lanes_active = false;           // the launch is part of a two-lane batch (api.hip, run_in_lanes): the other lane's kernels already
+                                         // spread the store bursts, the default de-phasing only costs time there (12.22 -> 12.16 ms per step)
     unsigned long long* gemm_tl = nullptr;   // debug timeline buffer (option gemm_timeline)
     bool attn_mfma = true;
     bool conv1_zero_skip = true;

@@ -876,7 +876,7 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStr
     // once the outputs were nontemporal the epilogues became HBM-write-burst bound (every CU stores its 128 KB at the
     // same moment) and spreading them pays: qkv 157 -> 146 us.  Only for long plain GEMMs (>= 4 rounds); the LN-fused
     // and conv kernels and short launches measured neutral or slower.  Option gemm_stagger: ticks of 10 ns, -1 = off.
-    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger : (!CONV && tiles >= 4 * o.num_cu ? 200 : 0);
+    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger : (!CONV && tiles >= 4 * o.num_cu && !o.lanes_active ? 200 : 0);
     hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
                        o.gemm_counted | (stagger << 8), o.gemm_tl);
     if (o.gemm_tl) dump_timeline(o, s, CONV ? "conv" : "linear");
