@@ -95,7 +95,8 @@ struct GemmArgs {
 // ---- tiled token stream (N = 512 columns, row tiles of 128) -----------------------------------------------------
 // The residual stream of the fused transformer is kept as fp16 + an 8-bit correction instead of fp32 (3 instead of
 // 4 bytes per element to read, 3 instead of 6 to write next to the fp16 copy the next GEMM needs anyway):
-//   x  =  x16 + q * ulp(x16)/256,   q = round((x - x16) * 256/ulp(x16)) in [-127, 127]
+//   x  =  x16 + (b - 128) * ulp(x16)/256,   b = sat_u8(rne(128 + (x - x16) * 256/ulp(x16)))  (one byte, biased)
+// (b - 128 in [-128, 127]; +128 saturates to 127: one unit of error on an exact +1/2 ulp tie)
 // i.e. 8 more mantissa bits than fp16 (relative error <= 2^-19 per LayerNorm output, 12 of them per forward pass;
 // the embedding tolerance is 1e-3).  Both planes are stored in the MFMA fragment order of the 128x512 LN kernel:
 //   x16t element (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + ((n&63)>>4)*256 + (m&15)*16 + (n&15),  R = m>>7
@@ -104,16 +105,29 @@ struct GemmArgs {
 //   d8t  byte    (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + lane*16 + ((n&63)>>4)*4 + (n&3),
 //        lane = ((n&15)>>2)*16 + (m&15)   (one 16-byte access per lane and 16-row block)
 #ifdef __HIPCC__
-__device__ __forceinline__ float res_dec(f16 h, int q) {
-    unsigned E = ((unsigned)__builtin_bit_cast(unsigned short, h) >> 10) & 31u;
-    E = E ? E : 1u;
-    return (float)h + (float)q * __builtin_bit_cast(float, (E + 94u) << 23);            // 2^(E-33) = ulp(h)/256
+// ulp(h)/256 = 2^(E-33) with E = max(exponent field of h, 1): the exponent bits of h alone are the fp16 number 2^(E-15), whose
+// conversion to fp32 is exact -- no shifts on the exponent field.  b: the stored byte (0..255).
+__device__ __forceinline__ float res_pow(f16 h) {                 // 2^(E-15)
+    unsigned short m = __builtin_bit_cast(unsigned short, h) & 0x7C00u;
+    m = m > 0x0400u ? m : (unsigned short)0x0400u;
+    return (float)__builtin_bit_cast(f16, m);
 }
-__device__ __forceinline__ int res_enc(float y, f16 h) {
-    unsigned E = ((unsigned)__builtin_bit_cast(unsigned short, h) >> 10) & 31u;
-    E = E ? E : 1u;
-    const float q = rintf((y - (float)h) * __builtin_bit_cast(float, (160u - E) << 23));   // * 2^(33-E)
-    return (int)fminf(fmaxf(q, -127.f), 127.f);
+__device__ __forceinline__ float res_dec(f16 h, unsigned b) {
+    const float u = res_pow(h) * 3.814697265625e-06f;             // 2^-18  ->  2^(E-33)
+    return __builtin_fmaf((float)b, u, __builtin_fmaf(-128.f, u, (float)h));       // exact: 19 significant bits
+}
+// four corrections packed into one dword: v_cvt_pk_u8_f32 rounds to nearest even, saturates to 0..255 and inserts the byte
+__device__ __forceinline__ unsigned res_enc4(float y0, float y1, float y2, float y3, f16 h0, f16 h1, f16 h2, f16 h3) {
+    auto t = [](float y, f16 h) -> float {
+        const float r = __builtin_bit_cast(float, 0x88000000u - __builtin_bit_cast(unsigned, res_pow(h)));     // 2^(33-E)
+        return __builtin_fmaf(y - (float)h, r, 128.f);
+    };
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y0, h0), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y1, h1), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y2, h2), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y3, h3), 3, w);
+    return w;
 }
 #endif
 

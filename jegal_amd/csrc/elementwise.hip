@@ -179,8 +179,7 @@ __global__ __launch_bounds__(256) void window_gather_tiled_kernel(const float* _
         v += *reinterpret_cast<const f32x4*>(pes + 16 * q);
         const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
         if (live) __builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(x16 + base + q * 256 + m15 * 16 + 4 * ng));
-        dq[q] = (unsigned)(res_enc(v.x, h[0]) & 0xff) | ((unsigned)(res_enc(v.y, h[1]) & 0xff) << 8) |
-                ((unsigned)(res_enc(v.z, h[2]) & 0xff) << 16) | ((unsigned)(res_enc(v.w, h[3]) & 0xff) << 24);
+        dq[q] = res_enc4(v.x, v.y, v.z, v.w, h[0], h[1], h[2], h[3]);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (live) __builtin_nontemporal_store(u32x4{dq[0], dq[1], dq[2], dq[3]}, reinterpret_cast<u32x4*>(d8 + base + lane * 16));

@@ -496,8 +496,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 const unsigned dw[4] = {asu(a3.x), asu(a3.y), asu(a3.z), asu(a3.w)};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[i][j] = f32x4{res_dec(h2(xw[i][0], 0), (int)(signed char)(dw[i] & 0xff)), res_dec(h2(xw[i][0], 1), (int)(signed char)((dw[i] >> 8) & 0xff)),
-                                      res_dec(h2(xw[i][1], 0), (int)(signed char)((dw[i] >> 16) & 0xff)), res_dec(h2(xw[i][1], 1), (int)(signed char)(dw[i] >> 24))};
+                    acc[i][j] = f32x4{res_dec(h2(xw[i][0], 0), dw[i] & 0xffu), res_dec(h2(xw[i][0], 1), (dw[i] >> 8) & 0xffu),
+                                      res_dec(h2(xw[i][1], 0), (dw[i] >> 16) & 0xffu), res_dec(h2(xw[i][1], 1), dw[i] >> 24)};
             }
         }
         for (int kt = 0; kt < nk; ++kt) {
@@ -656,8 +656,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                                     *reinterpret_cast<const f32x4*>(lnp + 2 * BN + ncol + i * 16);
                     const f16x4 hv = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
                     *reinterpret_cast<f16x4*>(o16 + j * 1024 + i * 256) = hv;
-                    const unsigned dw = (unsigned)(res_enc(y.x, hv[0]) & 0xff) | ((unsigned)(res_enc(y.y, hv[1]) & 0xff) << 8) |
-                                        ((unsigned)(res_enc(y.z, hv[2]) & 0xff) << 16) | ((unsigned)(res_enc(y.w, hv[3]) & 0xff) << 24);
+                    const unsigned dw = res_enc4(y.x, y.y, y.z, y.w, hv[0], hv[1], hv[2], hv[3]);
                     if (i == 0) dq.x = dw; else if (i == 1) dq.y = dw; else if (i == 2) dq.z = dw; else dq.w = dw;
                 }
                 *reinterpret_cast<uint4*>(o8 + j * 1024) = dq;
