@@ -374,8 +374,8 @@ __global__ __launch_bounds__(64 * NB) void attn_mfma_kernel(const f16* __restric
         const int c = tid + NT * r, row = c >> 3, part = c & 7;          // SP rows x 8 chunks = 4 * NT
         const int rc = row < S ? row : S - 1;
         const f16* src = base + (long)rc * ld + part * 8;
-        const f16x8 kk = *reinterpret_cast<const f16x8*>(src + D);
-        const f16x8 vv = *reinterpret_cast<const f16x8*>(src + 2 * D);
+        const f16x8 kk = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(src + D));
+        const f16x8 vv = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(src + 2 * D));
         *reinterpret_cast<f16x8*>(sK + row * K_PITCH + part * 16) = kk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(sVt + (part * 8 + e) * VT_PITCH + row * 2) = vv[e];

@@ -643,10 +643,12 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
     for (int r = wave; r < IH; r += 4) {
         if (!rowz[r]) continue;                                      // wave-uniform
         const uint8_t* row = fb + (size_t)r * (IW * 3);
-        uint4 v = *reinterpret_cast<const uint4*>(row + lane * 16);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // a row that turns out to be zero is never read again (conv1 skips it): keep it out of the caches
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + lane * 16));
         unsigned nz = v.x | v.y | v.z | v.w;
         if (lane < 26) {
-            v = *reinterpret_cast<const uint4*>(row + 1024 + lane * 16);
+            v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + 1024 + lane * 16));
             nz |= v.x | v.y | v.z | v.w;
         }
         if (__builtin_amdgcn_ballot_w64(nz != 0) != 0 && lane == 0) rowz[r] = 0;

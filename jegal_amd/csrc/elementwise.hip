@@ -268,7 +268,7 @@ __global__ void group_mean_kernel(const f16* __restrict__ in, int groups, int L,
         const long g = idx / dv;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = 0; j < L; ++j) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(in + (g * L + j) * D + d8 * 8);
+            const f16x8 v = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(in + (g * L + j) * D + d8 * 8));      // read once
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
         }
