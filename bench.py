@@ -112,8 +112,10 @@ def cpu_baseline(clips_u8, n_windows=96):
                               "what": f"same port with the conv stack evaluated once per padded-clip position (exact), {n_clips} whole clips in {t_dd:.1f} s"}}
 
 
-def launch_ranks(args, argv):
-    """--gpus N > 1 outside torchrun: start N fresh rank processes (one per GPU).  This parent never touches the GPU."""
+def launch_ranks(args, argv, timeout_s=1800.0):
+    """--gpus N > 1 outside torchrun: start N fresh rank processes (one per GPU).  This parent never touches the GPU.
+    Watchdog: the children are polled; when one exits non-zero (e.g. before the rendezvous) the others are terminated instead
+    of being left to wait for the process-group timeout, and the whole job has an overall time limit."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -125,13 +127,40 @@ def launch_ranks(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)     # rank 0's pipe must keep draining
+    reader.start()
+    deadline = time.monotonic() + timeout_s
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs):
+            why = "a rank failed"
+        elif time.monotonic() > deadline:
+            why = f"no result after {timeout_s:.0f} s"
+        if why:
+            for p in procs:                      # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10.0)
+    rcs = [p.returncode for p in procs]
+    sys.stdout.write(b"".join(out_chunks).decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+    if bad or why:
+        sys.stderr.write(f"bench.py: {why or 'ranks failed'}; (rank, exit code): {bad}\n")
         sys.exit(1)
 
 

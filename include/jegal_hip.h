@@ -75,8 +75,15 @@ int jg_sync(jg_handle* h);
  *      ignored, missing hot-path keys make jg_finalize_weights fail (strict). ------------------- */
 int jg_load_tensor(jg_handle* h, const char* name, const void* data_host, const int64_t* shape_host, int ndim, int dtype);
 /* which: bit 0 = GestSync, bit 1 = JEGAL, bit 2 = XLM-RoBERTa (keys of transformers.XLMRobertaModel under the prefix "xlmr.").
- * Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo. */
+ * Folds BatchNorm, packs k=(kh,kw,c), splits hi/lo.
+ * Staged tensors: the ones this call consumed are dropped; tensors staged for a model that is finalized by a LATER call stay
+ * (load everything, then finalize(1), finalize(2) works); keys no finalize consumes stay until jg_clear_staged_tensors.
+ * JG_PREC_FP16_BC: the built-in calibration runs for the gesture models finalized by THIS call only (never for bit 2 alone);
+ * bias corrections of the other model - e.g. from jg_calibrate_gesture on real clips - are kept.  Re-finalizing a model
+ * discards ITS corrections: call jg_calibrate_gesture again after re-loading it. */
 int jg_finalize_weights(jg_handle* h, int which);
+/* Drop every staged host tensor (the unused net_aud / lstm tensors of a GestSync checkpoint, tensors of a model never finalized). */
+int jg_clear_staged_tensors(jg_handle* h);
 
 /* Re-run the JG_PREC_FP16_BC calibration on caller-supplied clips (same layout as jg_gestsync_clip; device
  * pointer) instead of the built-in synthetic ones, e.g. a few real videos.  frames == NULL: built-in clips. */
@@ -104,6 +111,9 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
 int jg_debug_conv2_rowskip(jg_handle* h, int* rows);
 /* Tuning aid: ms per launch of the production GEMM for a shape (mode bit0 hi+lo weights, bit1 fp32 residual in/out, bit2 ReLU). */
 int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms);
+/* The same with caller-supplied fp16 operands a16 [M][K] / w16 [N][K] (device pointers; NULL: constant fill).  Constant operands
+ * flatter any MFMA kernel (the chip holds a higher clock on them): tools/gemm_yardstick.py times random data on both sides. */
+int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int N, int K, int mode, int iters, double* ms);
 /* Drop-in for GestSync.forward_vid(x, return_feats) (gestsync.py:148-162): x (N,3,25,270,480) fp32
  * -> out (N,1024,21) fp32, optional out_conv (N,512,21) fp32 (NULL to skip). */
 int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* out_conv);

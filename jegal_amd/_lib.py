@@ -29,11 +29,13 @@ _SIGS = {
     "jg_sync": [_P],
     "jg_load_tensor": [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I, _I],
     "jg_finalize_weights": [_P, _I],
+    "jg_clear_staged_tensors": [_P],
     "jg_calibrate_gesture": [_P, _P, _I, _I, _I],
     "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
     "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
     "jg_debug_gemm": [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
+    "jg_debug_gemm_ex": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
     "jg_debug_conv2_rowskip": [_P, ctypes.POINTER(ctypes.c_int)],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
@@ -162,9 +164,13 @@ class Engine:
             shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
             self._ck(self.lib.jg_load_tensor(self.h, name.encode(), arr.ctypes.data_as(_P), shape, arr.ndim, code))
 
-    def finalize(self, which):
+    def finalize(self, which, clear_staged=True):
+        """jg_finalize_weights; the Python facades load one model's state_dict and finalize it at once, so whatever that
+        finalize did not consume (net_aud.*, lstm.* of a GestSync checkpoint) is dropped afterwards."""
         with torch.cuda.device(self.device):
             self._ck(self.lib.jg_finalize_weights(self.h, which))
+        if clear_staged:
+            self._ck(self.lib.jg_clear_staged_tensors(self.h))
         self.finalized |= which
 
     # ---- helpers
@@ -225,10 +231,14 @@ class Engine:
         self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
         return out
 
-    def debug_gemm(self, M, N, K, mode=0, iters=10):
+    def debug_gemm(self, M, N, K, mode=0, iters=10, a16=None, w16=None):
+        """ms per launch of the production GEMM; a16 (M,K) / w16 (N,K): optional fp16 cuda operands (else constant fill)."""
         self._bind_stream()
         ms = ctypes.c_double()
-        self._ck(self.lib.jg_debug_gemm(self.h, M, N, K, mode, iters, ctypes.byref(ms)))
+        for t, shp in ((a16, (M, K)), (w16, (N, K))):
+            if t is not None and (t.dtype != torch.float16 or tuple(t.shape) != shp or not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"debug_gemm operand must be a contiguous fp16 {shp} tensor on {self.device}")
+        self._ck(self.lib.jg_debug_gemm_ex(self.h, _ptr(a16), _ptr(w16), M, N, K, mode, iters, ctypes.byref(ms)))
         return ms.value
 
     def debug_conv2_rowskip(self):

@@ -15,6 +15,7 @@ namespace {
 struct HostTensor {
     std::vector<float> v;
     std::vector<int64_t> shape;
+    mutable bool used = false;      // consumed by a finalize (find / need): erased when that finalize is done
     int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 
@@ -196,7 +197,9 @@ int wsalloc(jg_handle* h, size_t n, T** out) {
 
 const HostTensor* find(jg_handle* h, const std::string& name) {
     auto it = h->host.find(name);
-    return it == h->host.end() ? nullptr : &it->second;
+    if (it == h->host.end()) return nullptr;
+    it->second.used = true;
+    return &it->second;
 }
 
 int need(jg_handle* h, const std::string& name, int64_t numel, const HostTensor** out) {
@@ -815,11 +818,12 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
 // gesture path with hi+lo weights on a small batch, records E[x] of every Linear input, and folds that term into the
 // bias.  Run-time GEMMs then use single fp16 weights (half the MFMAs and LDS traffic of the hi+lo split) at the split's
 // accuracy (oracle/precision_probe.py).
-int apply_bias_corrections(jg_handle* h) {
+int apply_bias_corrections(jg_handle* h, int models) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::vector<float> mu;
     for (Lin* L : h->bc_layers) {
         if (L->mu_rows <= 0) continue;
+        if (!((models >> (L->model - 1)) & 1)) { L->mu_rows = 0; continue; }
         mu.resize(L->K);
         HIPCHK(h, hipMemcpy(mu.data(), L->mu, sizeof(float) * L->K, hipMemcpyDeviceToHost));
         std::vector<float> nb(L->N);
@@ -839,7 +843,9 @@ int apply_bias_corrections(jg_handle* h) {
 
 // frames == nullptr: built-in deterministic calibration clips (uniform u8 noise, rows 0..109 zeroed like the
 // face-mask rectangle), so results do not depend on what the engine happens to see first.
-int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T) {
+// models: bit 0 GestSync, bit 1 JEGAL -- only the bias-corrected layers of these models receive new corrections (the pass
+// itself always runs the whole gesture path: JEGAL's input means depend on GestSync's output)
+int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T, int models) {
     if (h->bc_layers.empty()) return JG_OK;
     void* own = nullptr;
     if (!frames) {
@@ -882,7 +888,7 @@ int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T) {
         rc = jegal_gestures_impl(h, feats, nullptr, B, T, 1, emb);
     }
     h->calib = false;
-    if (rc == JG_OK) rc = apply_bias_corrections(h);
+    if (rc == JG_OK) rc = apply_bias_corrections(h, models);
     hipStreamSynchronize(h->stream);
     hipFree(feats);
     hipFree(emb);
@@ -1075,8 +1081,12 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part) {
         h->opts.lanes_active = false;
         std::swap(h->ws, h->lane_ws[l]);
         h->stream = user;
-        if (rc == JG_OK && (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess ||
-                            hipStreamWaitEvent(user, h->lane_ev[1 + l], 0) != hipSuccess)) rc = JG_ERR_HIP;
+        // the join is unconditional: when run_part failed half way, the kernels it did enqueue on the lane still read the caller's
+        // frames / write its output, and the caller's stream must stay ordered behind them (it may free both right after the error)
+        if (hipEventRecord(h->lane_ev[1 + l], h->lane_stream[l]) != hipSuccess || hipStreamWaitEvent(user, h->lane_ev[1 + l], 0) != hipSuccess) {
+            (void)hipStreamSynchronize(h->lane_stream[l]);
+            if (rc == JG_OK) rc = JG_ERR_HIP;
+        }
     }
     if (rc == JG_ERR_HIP && h->err.empty()) h->err = "lane stream / event call failed";
     return rc;
@@ -1224,10 +1234,19 @@ int jg_finalize_weights(jg_handle* h, int which) {
     if (which & 1) { RET(finalize_gestsync(h)); RET(gs_build_const_chain(h)); }
     if (which & 2) RET(finalize_jegal(h));
     if (which & 4) RET(finalize_xlmr(h));
-    // the fp32 host copies of the checkpoint (incl. the unused audio/LSTM tensors of gestsync.py:23-32) are no longer
-    // needed: packed device weights + the w32/b32 of the bias-corrected layers carry everything
+    // The fp32 host copies this finalize consumed are no longer needed (packed device weights + the w32/b32 of the
+    // bias-corrected layers carry everything).  Tensors staged for a model that is finalized LATER stay staged; what no
+    // finalize consumes (the unused audio/LSTM tensors of gestsync.py:23-32) stays until jg_clear_staged_tensors / jg_destroy.
+    for (auto it = h->host.begin(); it != h->host.end();) it = it->second.used ? h->host.erase(it) : std::next(it);
+    // Built-in calibration only for the gesture models finalized by THIS call (XLM-R has no bias-corrected layers): the bias
+    // corrections of the other model -- possibly from jg_calibrate_gesture on real clips -- are left as they are.
+    if (h->precision == JG_PREC_FP16_BC && (which & 3)) RET(calibrate_impl(h, nullptr, JG_U8, 0, 0, which & 3));
+    return JG_OK;
+}
+
+int jg_clear_staged_tensors(jg_handle* h) {
+    if (!h) return JG_ERR_ARG;
     h->host.clear();
-    if (h->precision == JG_PREC_FP16_BC) RET(calibrate_impl(h, nullptr, JG_U8, 0, 0));
     return JG_OK;
 }
 
@@ -1235,7 +1254,7 @@ int jg_calibrate_gesture(jg_handle* h, const void* frames, int dtype, int B, int
     ENTER(h);
     if (h->precision != JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC");
     if (frames && (B <= 0 || T <= 0 || (dtype != JG_U8 && dtype != JG_F32))) JG_FAIL(h, JG_ERR_ARG, "bad calibration batch");
-    return calibrate_impl(h, frames, dtype, B, T);
+    return calibrate_impl(h, frames, dtype, B, T, 3);
 }
 
 int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, float* out) {
@@ -1252,7 +1271,8 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, 
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16) {
     ENTER(h);
     if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
-    if (!frames_u8 || !out_f16 || B <= 0 || T + 2 * pad < 5) JG_FAIL(h, JG_ERR_ARG, "bad arguments");
+    if (!frames_u8 || !out_f16 || B <= 0 || pad < 0 || pad > 12 || T + 2 * pad < 5)      // conv1's skip-mask area is sized for pad <= 12
+        JG_FAIL(h, JG_ERR_ARG, "bad arguments (need 0 <= pad <= 12 and T + 2*pad >= 5)");
     h->ws.reset();
     const int P = T + 2 * pad - 4;
     const long NF = (long)B * P;
@@ -1277,6 +1297,12 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
 // Tuning aid: time `iters` launches of the production GEMM on garbage operands of a given shape.
 // mode bit 0: hi+lo weights, bit 1: fp32 residual in/out (else fp16 out), bit 2: ReLU.  Returns ms per launch in *ms.
 int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms) {
+    return jg_debug_gemm_ex(h, nullptr, nullptr, M, N, K, mode, iters, ms);
+}
+
+// a16 / w16: caller-supplied fp16 operands ([M][K] and [N][K], e.g. random data: constant operands let the chip hold a higher
+// clock than real data does, MI355X_MICROARCH.md "DVFS give-back"); NULL: constant fill
+int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int N, int K, int mode, int iters, double* ms) {
     if (!h || !ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return JG_ERR_ARG;
     ENTER(h);
     h->ws.reset();
@@ -1288,8 +1314,10 @@ int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double
     RET(wsalloc(h, pad128(M) * N, &o16));
     RET(wsalloc(h, pad128(M) * N, &x32));
     RET(wsalloc(h, (size_t)N, &bias));
-    HIPCHK(h, hipMemsetAsync(A, 0x3c, (size_t)M * K * 2, h->stream));
-    HIPCHK(h, hipMemsetAsync(Wh, 0x2c, (size_t)N * K * 2, h->stream));
+    if (a16) HIPCHK(h, hipMemcpyAsync(A, a16, (size_t)M * K * 2, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(A, 0x3c, (size_t)M * K * 2, h->stream));
+    if (w16) HIPCHK(h, hipMemcpyAsync(Wh, w16, (size_t)N * K * 2, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(h, hipMemsetAsync(Wh, 0x2c, (size_t)N * K * 2, h->stream));
     HIPCHK(h, hipMemsetAsync(Wl, 0x1c, (size_t)N * K * 2, h->stream));
     HIPCHK(h, hipMemsetAsync(bias, 0, (size_t)N * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(x32, 0, (size_t)M * N * 4, h->stream));
@@ -1442,9 +1470,9 @@ int jg_asd(jg_handle* h, const float* q, const float* cand, const int32_t* coff,
 
 int jg_profile_enable(jg_handle* h, int on) {
     if (!h) return JG_ERR_ARG;
+    if (on < 0 || on - 2 >= JG_ST_COUNT) JG_FAIL(h, JG_ERR_ARG, "bad stage");      // validated before anything changes
     h->prof = on != 0;
     h->prof_only = on >= 2 ? on - 2 : -1;
-    if (h->prof_only >= JG_ST_COUNT) JG_FAIL(h, JG_ERR_ARG, "bad stage");
     return JG_OK;
 }
 

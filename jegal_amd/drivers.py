@@ -38,19 +38,45 @@ def load_checkpoint(path, kind):
     return {k.replace("module.", ""): v for k, v in sd.items()}
 
 
+def _add_precision_args(p):
+    p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3],
+                   help="engine precision mode (include/jegal_hip.h); default: 3 (bias-corrected fp16) for the seeded synthetic "
+                        "weights or when --calibrate_frames is given, 1 (hi+lo fp16 Linear weights, calibration-free) for real checkpoints")
+    p.add_argument("--calibrate_frames", default=None,
+                   help=".npy of masked uint8 crops (B,T,270,480,3) or (T,270,480,3): re-run the precision-mode-3 calibration on them")
+
+
+def pick_precision(args, checkpoints):
+    """The default precision mode folds (w - fp16(w)).E[x] into every Linear bias, with E[x] recorded on built-in synthetic clips.
+    That calibration was only ever validated on the synthetic weights (no checkpoints ship with the reference), so a REAL
+    checkpoint gets the calibration-free hi+lo mode unless the caller supplies calibration clips."""
+    from ._lib import PREC_FP16_BC, PREC_FP16_W2
+    if getattr(args, "precision", None) is not None:
+        return args.precision
+    real = any(c is not None and c != "synthetic" for c in checkpoints)
+    return PREC_FP16_W2 if real and not getattr(args, "calibrate_frames", None) else PREC_FP16_BC
+
+
 def _models(args, need_gestsync=False, need_jegal=False):
-    from ._lib import Engine
+    from ._lib import Engine, PREC_FP16_BC
     from .gestsync import GestSync
     from .jegal import JEGAL
     jdist.init_from_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     eng = Engine.get()
+    prec = pick_precision(args, [getattr(args, "checkpoint_path_gestsync", None) if need_gestsync else None,
+                                 getattr(args, "checkpoint_path", None) if need_jegal else None])
+    if eng.finalized == 0:
+        eng.set_precision(prec)
     gs = jg = None
     if need_gestsync:
         gs = GestSync(engine=eng).load_state_dict(load_checkpoint(args.checkpoint_path_gestsync, "gestsync"))
     if need_jegal:
         jg = JEGAL(engine=eng).load_state_dict(load_checkpoint(args.checkpoint_path, "jegal"))
+    if getattr(args, "calibrate_frames", None) and prec == PREC_FP16_BC and need_gestsync:
+        clips = np.load(args.calibrate_frames)
+        eng.calibrate(torch.from_numpy(clips if clips.ndim == 5 else clips[None]).to(eng.device))
     return eng, gs, jg
 
 
@@ -64,6 +90,7 @@ def cmd_extract_gestsync_feats(argv):
     p.add_argument("--clips_per_batch", type=int, default=8)
     p.add_argument("--rank", type=int, default=None)
     p.add_argument("--nshard", type=int, default=None)
+    _add_precision_args(p)
     args = p.parse_args(argv)
     eng, gs, _ = _models(args, need_gestsync=True)
     files = sorted(glob.glob(os.path.join(args.frames_dir, "*", "*.npy")))
@@ -110,6 +137,7 @@ def cmd_extract_jegal_embs(argv):
     p.add_argument("--text_states_dir", default=None)
     p.add_argument("--modalities", default="vta", choices=["vta", "vt", "va", "ta", "v", "t", "a"])
     p.add_argument("--batch_size", type=int, default=16)
+    _add_precision_args(p)
     args = p.parse_args(argv)
     eng, _, jg = _models(args, need_jegal=True)
     df = pd.read_csv(args.file_path)

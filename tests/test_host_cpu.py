@@ -185,3 +185,30 @@ def test_two_rank_gloo_sharded_retrieval(tmp_path):
             raise AssertionError(text)
     for rc, out in outs:
         assert " ok" in out
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """bench.py --gpus 2 without a torchrun environment starts the ranks itself; a rank that dies before the rendezvous (here:
+    no HIP device in this container) must take the job down promptly with a non-zero exit, not leave the launcher waiting for
+    the process-group timeout."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ranks would run")
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, timeout=170)
+    assert r.returncode != 0
+    assert b"rank" in r.stderr
+    assert time.monotonic() - t0 < 150
+
+
+def test_cli_drivers_pick_the_calibration_free_mode_for_real_checkpoints():
+    """the default bias-corrected mode depends on a calibration that was validated on the synthetic weights
+    only; a real checkpoint runs hi+lo (mode 1) unless calibration clips or an explicit --precision are given."""
+    from types import SimpleNamespace as NS
+    from jegal_amd.drivers import pick_precision
+    assert pick_precision(NS(precision=None, calibrate_frames=None), ["synthetic", None]) == 3
+    assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 1
+    assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/gestsync.pth"]) == 3
+    assert pick_precision(NS(precision=0, calibrate_frames=None), ["/ckpt/jegal.pth"]) == 0
