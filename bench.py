@@ -112,6 +112,83 @@ def cpu_baseline(clips_u8, n_windows=96):
                               "what": f"same port with the conv stack evaluated once per padded-clip position (exact), {n_clips} whole clips in {t_dd:.1f} s"}}
 
 
+CONTENT_GFLOP_PER_CLIP = 2.15 + 0.52 + 0.02       # JEGAL audio CNN / text encoder (L = 12) / fusion + align (W = 10)
+
+
+def config3(eng, jg, dev, steps, warmup=3, clips=64):
+    """BASELINE configs[2] / SURVEY 8d config 3: B = 64 tri-modal (seeds 1234 / 1235 / 1236) end to end on one GPU:
+    frames -> GestSync features -> JEGAL.forward_inference(visual, text, audio) -> L2-normalised (gesture, content).
+    Returns clips/s of the whole vta step, per-branch milliseconds (torch events on the engine's stream) and the content
+    path's share."""
+    import numpy as np
+    import torch
+    from jegal_amd import synth
+    B, T, W = clips, FRAMES, 10
+    frames = torch.from_numpy(synth.synth_frames(1234, B, T)).to(dev)
+    mel = torch.from_numpy(synth.synth_mel(1235, B, 4 * T)).to(dev)
+    states, tmask, ids, offs = synth.synth_text(1236, B, W)
+    wbs = synth.synth_boundaries(B, W)
+    tbatch = [[w[0] for w in wb] for wb in wbs]
+    st_d, tm_d = torch.from_numpy(states).to(dev), torch.from_numpy(tmask.astype(np.float32)).to(dev)
+    vmask = torch.ones((B, T), dtype=torch.float32, device=dev)
+    pack = (st_d, tm_d, tbatch, ids, offs)
+
+    def step():
+        feats = eng.gestsync_clip(frames)
+        g, c = jg.forward_inference(visual_feats=feats, visual_mask=vmask, text=pack, audio=mel, word_boundaries=wbs)
+        return eng.l2norm(g.reshape(B * T, 512)), eng.l2norm(c.reshape(-1, 512))
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g, c = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(g).all() and torch.isfinite(c).all()
+
+    # per-branch times: the same calls bracketed with events (the host-side segment logic of the word pooling is inside
+    # its bracket: it is part of what a caller waits for)
+    from jegal_amd.jegal import audio_word_segments, text_word_segments
+    names = ["gestsync_features", "jegal_gesture_encoder", "audio_cnn", "text_encoder", "word_pool_fusion", "l2norm"]
+    acc = {n: 0.0 for n in names}
+    reps = 5
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        feats = eng.gestsync_clip(frames)
+        ev[1].record()
+        gest = eng.jegal_gestures(feats, vmask, align=True)
+        ev[2].record()
+        aud = eng.jegal_audio(mel)
+        ev[3].record()
+        sub = eng.jegal_text(st_d, tm_d)
+        ev[4].record()
+        t_segs, _ = text_word_segments(ids, offs, tbatch)
+        a_segs = audio_word_segments(wbs, aud.shape[1])
+        fused = torch.zeros((B, W, 512), dtype=torch.float32, device=dev)
+        jg._pool(aud, a_segs, 0, fused, list(range(B)))
+        jg._pool(sub, t_segs, 256, fused, list(range(B)))
+        cont = eng.fuse_content(fused)
+        ev[5].record()
+        eng.l2norm(gest.reshape(B * T, 512)); eng.l2norm(cont.reshape(-1, 512))
+        ev[6].record()
+        torch.cuda.synchronize()
+        for i, n in enumerate(names):
+            acc[n] += ev[i].elapsed_time(ev[i + 1]) / reps
+    content_ms = acc["audio_cnn"] + acc["text_encoder"] + acc["word_pool_fusion"]
+    total_ms = dt / steps * 1e3
+    return {"workload": "BASELINE configs[2]: synthetic batch=64 vta (frames seed 1234, mel seed 1235 (64,600,80), text states seed 1236 "
+                        "(64,12,768), W = 10 words), resident in HBM, one GPU",
+            "value": B * steps / dt, "unit": "clips/s", "ms_per_step": total_ms, "steps": steps, "clips": B,
+            "branch_ms": {k: round(v, 3) for k, v in acc.items()},
+            "content_path_ms": round(content_ms, 3), "content_path_share_of_step": content_ms / total_ms,
+            "content_path_mfma_frac": CONTENT_GFLOP_PER_CLIP * B / max(content_ms, 1e-9) / MFMA_PEAK_TFLOPS,
+            "note": "branch_ms: torch events around the library calls in a separate pass; content path = audio CNN + text encoder + "
+                    "word pooling (host segment logic included) + fusion / align MLPs"}
+
+
 def launch_ranks(args, argv, timeout_s=1800.0):
     """--gpus N > 1 outside torchrun: start N fresh rank processes (one per GPU).  This parent never touches the GPU.
     Watchdog: the children are polled; when one exits non-zero (e.g. before the rendezvous) the others are terminated instead
@@ -178,6 +255,7 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing aid: allow more ranks than GPUs (ranks share devices round-robin; forces backend gloo; flagged in the output)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tuning experiments)")
+    ap.add_argument("--only", default=None, choices=["config3"], help="run just one secondary measurement (for rocprofv3 summaries) and print its object")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -220,7 +298,10 @@ def main():
         k, v = o.split("=")
         eng.set_option(k, int(v))
     GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
-    JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    jg_model = JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    if args.only == "config3":
+        print(json.dumps({"config3": config3(eng, jg_model, dev, max(3, min(args.steps, 20)))}))
+        return
 
     frames_host = synth.synth_frames(1234 + rank, args.clips, FRAMES)
     frames = torch.from_numpy(frames_host).to(dev)
@@ -231,11 +312,12 @@ def main():
         jdist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(n):
+    def timed_loop(n, src=None):
+        src = frames if src is None else src
         sync_all()
         t0 = time.perf_counter()
         for _ in range(n):
-            eng.extract_gesture(frames, out)
+            eng.extract_gesture(src, out)
         sync_all()
         tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         jdist.all_reduce_max(tmax)
@@ -275,7 +357,8 @@ def main():
 
     c1_ms, c1_n = profiled(only="conv1")["conv1"]
     prof = profiled()
-    conv2_rows_skipped = eng.debug_conv2_rowskip()          # of 20 output rows per position ("conv2_row_skip", bit-identical)
+    conv2_rows_skipped = eng.debug_conv2_rowskip()          # min over the positions, of 20 output rows ("conv2_row_skip", bit-identical)
+    conv_rows, conv_rows_full = eng.debug_conv_rows()       # output pixels conv2 .. conv5 computed / would compute without the skip
 
     extras = {}
     if not args.no_extras:
@@ -284,6 +367,23 @@ def main():
         dprof = profiled(only="conv1", src=dense)
         del dense
         extras["dense_ms"], extras["dense_n"] = dprof["conv1"]
+        # robustness of the headline to the mask: the same timed loop on (a) clips whose mask height is drawn per
+        # frame from 80..140 rows (the reference's rectangle follows the chin; every position skips what ITS frames allow) and
+        # (b) clips without any zero row (nothing is skipped anywhere)
+        fj = torch.from_numpy(synth.synth_frames(1234 + rank, args.clips, FRAMES, mask_jitter=(80, 140))).to(dev)
+        for _ in range(3):
+            eng.extract_gesture(fj, out)
+        extras["jitter_s"] = timed_loop(args.steps, fj)
+        eng.set_option("dual_stream", 0)
+        eng.extract_gesture(fj, out)
+        extras["jitter_rows"] = eng.debug_conv_rows()
+        eng.set_option("dual_stream", 1 if dual else 0)
+        del fj
+        fd = torch.randint(1, 256, frames.shape, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            eng.extract_gesture(fd, out)
+        extras["dense_s"] = timed_loop(args.steps, fd)
+        del fd
         # sustained rate: whatever K the driver asked for, also run ~2.5 s of back-to-back steps (clocks settle)
         per = dt / max(args.steps, 1)
         n_sus = max(args.steps, int(2.5 / max(per, 1e-4)))
@@ -313,6 +413,8 @@ def main():
             m_single = M.metrics_from_ranks(r_all.cpu().numpy(), t_all.cpu().numpy())
             assert m_single == m_sharded, ("sharded retrieval metrics differ from the single-rank result", m_single, m_sharded)
             extras["retrieval"]["equals_single_rank"] = True
+            if world == 1:
+                extras["config3"] = config3(eng, jg_model, dev, max(3, min(args.steps, 20)))
             # PCIe-inclusive rate (host-resident clips -> pinned buffers -> H2D under compute -> D2H), never `value`
             if world == 1:
                 from jegal_amd.extract import GestureStreamer
@@ -340,12 +442,10 @@ def main():
         exec_frac = CONV1_EXECUTED_TILE_FRACTION if zskip else 1.0
         achieved = CONV1_GFLOP_PER_CLIP * exec_frac * clips_per_launch / c1_avg_s / 1e3 if c1_avg_s > 0 else 0.0
         traffic, traffic_note = load_traffic()
-        s2 = conv2_rows_skipped                 # conv3 and conv4 derive their counts from it (common.h, conv_skip_decode)
-        s3 = s2 // 2
-        s4 = max(s3 - 1, 0)
-        s5 = max(s3 - 2, 0)
-        conv_rest_exec = (CONV_REST_GFLOP_PER_CLIP - CONV2_GFLOP_PER_CLIP * s2 / 20.0 - CONV3_GFLOP_PER_CLIP * s3 / 10.0 -
-                          CONV4_GFLOP_PER_CLIP * s4 / 10.0 - CONV5_GFLOP_PER_CLIP * s5 / 10.0)
+        # executed share of conv2 .. conv5: every position leaves out its own position-independent leading rows (ConvGeom::rowmap)
+        cfrac = [conv_rows[l] / conv_rows_full[l] if conv_rows_full[l] else 1.0 for l in range(4)]
+        layer_gflop = [CONV2_GFLOP_PER_CLIP, CONV3_GFLOP_PER_CLIP, CONV4_GFLOP_PER_CLIP, CONV5_GFLOP_PER_CLIP]
+        conv_rest_exec = CONV_REST_GFLOP_PER_CLIP - sum(g * (1.0 - f) for g, f in zip(layer_gflop, cfrac))
         exec_gflop_clip = CONV1_GFLOP_PER_CLIP * exec_frac + conv_rest_exec + LINEAR_GFLOP_PER_CLIP
         stage = {k: v[0] / nprof for k, v in prof.items()}
         conv_ms = stage["conv1"] + stage["conv1_aux"] + stage["maxpool"] + stage["conv2-fc6+audio_cnn"] + stage["stack_frames"]
@@ -377,7 +477,8 @@ def main():
             # SURVEY 8d asks for BOTH fractions on the conv extractor: algorithmic HBM bytes of the whole conv stack / its time
             "roofline_conv_stack": {"bound": "mfma", "ms_per_step": conv_ms,
                                     "mfma_frac": (CONV1_GFLOP_PER_CLIP * exec_frac + conv_rest_exec) * args.clips / max(conv_ms, 1e-9) / MFMA_PEAK_TFLOPS,
-                                    "conv2_rows_skipped": conv2_rows_skipped, "conv3_rows_skipped": s3, "conv4_rows_skipped": s4, "conv5_rows_skipped": s5,
+                                    "conv2_rows_skipped_min": conv2_rows_skipped,
+                                    "computed_row_fraction": {f"conv{l + 2}": round(cfrac[l], 4) for l in range(4)},
                                     "flops_note": "executed FLOPs: conv1 tiles over all-zero input and the leading conv2 .. conv5 output rows that do "
                                                   "not depend on the position (read from images computed once per weight load) are not counted",
                                     "algorithmic_bytes_per_step": CONV_ALGO_BYTES_PER_CLIP * args.clips,
@@ -397,6 +498,15 @@ def main():
             da = CONV1_GFLOP_PER_CLIP * clips_per_launch / d1 / 1e3 if d1 > 0 else 0.0
             res["roofline"]["dense_input"] = {"what": "same launch on uniform-noise frames without zero rows (timing only): every tile computed",
                                               "launch_ms": d1 * 1e3, "achieved": da, "frac": da / MFMA_PEAK_TFLOPS}
+            jr, jf = extras["jitter_rows"]
+            res["value_jitter_mask"] = {"value": args.clips * world * args.steps / extras["jitter_s"], "unit": "clips/s",
+                                        "ms_per_step": extras["jitter_s"] / args.steps * 1e3,
+                                        "computed_row_fraction": {f"conv{l + 2}": round(jr[l] / jf[l], 4) if jf[l] else 1.0 for l in range(4)},
+                                        "what": "the same timed loop on the same clips with the mask height drawn per frame from 80..140 rows "
+                                                "(seed fixed; inference_embs.py:264-270 blanks rows 0..y2+15 per frame)"}
+            res["value_dense"] = {"value": args.clips * world * args.steps / extras["dense_s"], "unit": "clips/s",
+                                  "ms_per_step": extras["dense_s"] / args.steps * 1e3,
+                                  "what": "the same timed loop on uniform-noise clips without any zero row: no conv1 tile and no conv2..conv5 row is skipped"}
             res["sustained"] = {"steps": extras["sustained_steps"], "seconds": extras["sustained_s"],
                                 "value": args.clips * world * extras["sustained_steps"] / extras["sustained_s"], "unit": "clips/s"}
             if "single_stream_s" in extras:
@@ -404,6 +514,8 @@ def main():
                                         "value": args.clips * world * args.steps / extras["single_stream_s"], "unit": "clips/s",
                                         "what": "the same timed loop with dual_stream=0 (every batch on one stream); stage_ms_per_step and the roofline objects are measured in this mode"}
             res["retrieval_config4"] = extras["retrieval"]
+            if "config3" in extras:
+                res["config3"] = extras["config3"]
             if "pcie_clips_per_s" in extras:
                 res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",
                                          "what": "host-resident clips -> pinned buffers -> H2D under compute -> embeddings back on the host (GestureStreamer); never `value`"}

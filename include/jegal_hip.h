@@ -106,9 +106,13 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, 
 /* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,
  * pad = temporal edge padding (12 for clips, 0 for a raw 25-frame window) -> out (B*(T+2*pad-4),43,78,64) fp16 NHWC. */
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16);
-/* Check point for "conv2_row_skip": how many leading conv2 output rows per image the last conv stack left to the copy kernel
- * (0: none, or the option is off).  Synchronises the stream. */
+/* Check point for "conv2_row_skip": the MINIMUM over the positions of the last conv stack of the leading conv2 output rows that
+ * were read from the const chain instead of computed (every position skips its own count: jg_debug_conv_rows);
+ * 0: none, or the option is off.  Synchronises the stream. */
 int jg_debug_conv2_rowskip(jg_handle* h, int* rows);
+/* Check point for the per-position form of it: computed[l] / full[l] = output pixels (rows of the implicit GEMM) that conv2 .. conv5
+ * (l = 0..3) of the LAST conv stack computed / would compute without the skip (0 / 0: option off or path not taken).  Synchronises. */
+int jg_debug_conv_rows(jg_handle* h, int64_t* computed, int64_t* full);
 /* Tuning aid: ms per launch of the production GEMM for a shape (mode bit0 hi+lo weights, bit1 fp32 residual in/out, bit2 ReLU). */
 int jg_debug_gemm(jg_handle* h, int M, int N, int K, int mode, int iters, double* ms);
 /* The same with caller-supplied fp16 operands a16 [M][K] / w16 [N][K] (device pointers; NULL: constant fill).  Constant operands

@@ -37,6 +37,7 @@ _SIGS = {
     "jg_debug_gemm": [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
     "jg_debug_gemm_ex": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
     "jg_debug_conv2_rowskip": [_P, ctypes.POINTER(ctypes.c_int)],
+    "jg_debug_conv_rows": [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
     "jg_audio_len": [_I],
@@ -246,6 +247,12 @@ class Engine:
         rows = ctypes.c_int()
         self._ck(self.lib.jg_debug_conv2_rowskip(self.h, ctypes.byref(rows)))
         return rows.value
+
+    def debug_conv_rows(self):
+        """(computed, full) output pixels of conv2 .. conv5 in the last conv stack (per-position row skip)."""
+        c, f = (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 4)()
+        self._ck(self.lib.jg_debug_conv_rows(self.h, c, f))
+        return list(c), list(f)
 
     def debug_conv1_pool(self, frames_u8, pad):
         """conv1+BN+ReLU+maxpool only: (B,T,270,480,3) u8 -> (B*(T+2*pad-4),43,78,64) fp16 NHWC."""

@@ -83,7 +83,9 @@ struct jg_handle {
     bool qkv0_linear = true;       // layer-0 qkv projection over the distinct conv positions + gather in the attention kernel
     bool ws_poison = false;        // option "ws_poison": fill the workspace with 0xff before every clip chunk (tests)
     bool conv2_row_skip = true;    // conv2 leaves out the leading output rows that the zero-band scan proves to be copies of one row
-    const int* last_rowskip = nullptr;   // device word the last conv stack's conv2 read its row skip from (jg_debug_conv2_rowskip)
+    const int* last_rowskip = nullptr;   // device word: min over the last conv stack's positions of conv2's row skip (jg_debug_conv2_rowskip)
+    const int* last_conv_totals = nullptr;   // device [4]: rows conv2 .. conv5 of the last conv stack computed (jg_debug_conv_rows)
+    long last_conv_full[4] = {0, 0, 0, 0};   // ... of these many
     std::map<std::string, HostTensor> host;
     std::vector<void*> wallocs_gs, wallocs_jg;   // device weights of the GestSync / JEGAL model (freed on re-finalize)
     std::vector<void*>* wallocs = &wallocs_gs;   // list the model being finalized allocates into
@@ -490,8 +492,8 @@ ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int P
     g.OW = (W + 2 * PW - KW) / SW + 1;
     g.cshift = 0;
     while ((1 << g.cshift) < C) ++g.cshift;
-    g.rowskip = nullptr; g.rowskip_op = 0;
-    g.in_rowskip = nullptr; g.in_op = 0;
+    g.rowmap = nullptr; g.rows_total = nullptr;
+    g.in_op = 0;
     g.const_in = nullptr;
     return g;
 }
@@ -517,6 +519,9 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     const int P = T + 2 * pad - 4;
     const long NF = (long)nclip * P;
     f16 *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
+    const int* s2pos = nullptr;          // per-position row-skip counts (direct path with conv2_row_skip)
+    h->last_rowskip = nullptr;
+    h->last_conv_totals = nullptr;
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);            // 88 x 158
     ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);            // 20 x 37   (taps in parity-class order, as packed)
     ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);           // 10 x 19
@@ -538,18 +543,32 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
         RET(wsalloc(h, conv1_zmask_elems(nclip, T), &zscr));
-        // Position-independent leading rows (common.h, ConvGeom::rowskip): the zero-band scan leaves conv2's count in zscr;
-        // conv2 / conv3 / conv4 leave those rows out and conv3 / conv4 / conv5 read them from the const chain.  Only the
-        // LDS-DMA conv kernel knows how, so every layer of the chain must take that path.
+        // Position-independent leading rows (common.h, ConvGeom::rowmap): the zero-band scan leaves every position's count s2 in
+        // zscr; conv2 .. conv5 leave those rows out PER POSITION (compacted row maps built on the device) and conv3 .. conv5 and the
+        // last max-pool read them from the const chain.  Only the LDS-DMA conv kernel knows how, so every layer of the chain must
+        // take that path.
         const bool rowskip = h->opts.conv1_zero_skip && h->conv2_row_skip && h->opts.gemm_glds && h->gs_c2C && NF * 10 * 10 >= 256 &&
                              NF * 20 * 37 < (1L << 24);
         RET(conv1_from_frames(h, static_cast<const uint8_t*>(src), nclip, T, pad, p1, edge, zscr, !rowskip));
         if (rowskip) {
-            const int* w = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
-            g2.rowskip = w; g2.rowskip_op = 0;
-            g3.rowskip = w; g3.rowskip_op = 1; g3.in_rowskip = w; g3.in_op = 0; g3.const_in = h->gs_c2C;
-            g4.rowskip = w; g4.rowskip_op = 2; g4.in_rowskip = w; g4.in_op = 1; g4.const_in = h->gs_c3C;
-            g5.rowskip = w; g5.rowskip_op = 3; g5.in_rowskip = w; g5.in_op = 2; g5.const_in = h->gs_c4C;
+            s2pos = conv1_s2_counts(zscr, nclip, T, pad);
+            ConvGeom* gs[4] = {&g2, &g3, &g4, &g5};
+            const f16* cin[4] = {nullptr, h->gs_c2C, h->gs_c3C, h->gs_c4C};
+            ConvRowMap rm[4];
+            int* totals;
+            RET(wsalloc(h, (size_t)64, &totals));
+            for (int l = 0; l < 4; ++l) {
+                rm[l].OH = gs[l]->OH; rm[l].OW = gs[l]->OW; rm[l].op = l;
+                RET(wsalloc(h, (size_t)NF * gs[l]->OH * gs[l]->OW, &rm[l].map));
+                RET(wsalloc(h, (size_t)NF + 1, &rm[l].base));
+                rm[l].total = totals + l;
+                gs[l]->rowmap = rm[l].map; gs[l]->rows_total = rm[l].total;
+                gs[l]->in_op = l - 1; gs[l]->const_in = cin[l];
+                h->last_conv_full[l] = NF * gs[l]->OH * gs[l]->OW;
+            }
+            RET(timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv_rowmaps(s2pos, (int)NF, rm, 4, h->stream); }));
+            h->last_conv_totals = totals;
+            h->last_rowskip = reinterpret_cast<const int*>(zscr) + CONV1_ROWSKIP_WORD;
         }
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
@@ -562,11 +581,10 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     }
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
-    h->last_rowskip = g2.rowskip;
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
     e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
-    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream, g5.rowskip, g5.rowskip_op, h->gs_c5C); }));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream, s2pos, 3, h->gs_c5C); }));
     e.out16 = conv16; e.out32 = conv_out;
     RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
     return JG_OK;
@@ -1200,6 +1218,18 @@ int jg_debug_conv2_rowskip(jg_handle* h, int* rows) {
     if (!h->last_rowskip) return JG_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(rows, h->last_rowskip, sizeof(int), hipMemcpyDeviceToHost));
+    return JG_OK;
+}
+
+int jg_debug_conv_rows(jg_handle* h, int64_t* computed, int64_t* full) {
+    ENTER(h);
+    if (!computed || !full) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    for (int l = 0; l < 4; ++l) computed[l] = full[l] = 0;
+    if (!h->last_conv_totals) return JG_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int t[4];
+    HIPCHK(h, hipMemcpy(t, h->last_conv_totals, sizeof(t), hipMemcpyDeviceToHost));
+    for (int l = 0; l < 4; ++l) { computed[l] = t[l]; full[l] = h->last_conv_full[l]; }
     return JG_OK;
 }
 

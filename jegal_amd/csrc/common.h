@@ -26,25 +26,33 @@ struct ConvGeom {
     // ---- position-independent leading rows (LDS-DMA conv kernels ONLY: api.hip sets these for launches that take that path).
     // Behind conv1's zero-band skip (conv1.hip) the first rows of every layer's output do not depend on the position at all:
     // they are what the layer computes from an all-constant input image, and the engine keeps those images per weight load
-    // ("const chain", api.hip).  A layer then leaves its first s rows out (rowskip) and its consumer reads the rows below s_in
-    // from the const image of its input instead (in_rowskip / const_in).  s = conv_skip_decode(*word, op): all layers share
-    // ONE device word (conv2's count, reduced over the launch by conv1_skip_mask_kernel) and derive their own count from it;
-    // the kernels read it at launch, the host never sees the value (no synchronisation).  nullptr: nothing is skipped.
-    const int* rowskip;       // producer side: leading output rows of every image that are NOT computed
-    int rowskip_op;
-    const int* in_rowskip;    // consumer side: leading INPUT rows of every image that were not computed by the producer ...
-    int in_op;
-    const f16* const_in;      // ... and the const image [H][W][C] of the input they are read from instead
+    // ("const chain", api.hip).  PER POSITION (image) p, conv2 leaves its first s2[p] output rows out and every deeper layer the
+    // count conv_skip_decode(s2[p], op) derived from it; a consumer reads the input rows its producer left out from the const
+    // image of its input instead.  The computed rows of a launch are COMPACTED: the kernel runs over m' = 0 .. *rows_total - 1 and
+    //   rowmap[m'] = (full output row = (img*OH + oh)*OW + ow) | s2[img] << 24
+    // gives it the pixel to compute, the row to store to and the image's count (launch_conv_rowmaps builds the maps on the
+    // device from conv1_skip_mask_kernel's per-position counts; the host never sees a value, nothing synchronises).
+    const int* rowmap;        // nullptr: every row is computed, m' = m
+    const int* rows_total;    // device word: number of compacted rows of this launch (read at kernel start)
+    int in_op;                // consumer side: input rows < conv_skip_decode(s2[img], in_op) were not computed by the producer ...
+    const f16* const_in;      // ... and are read from this const image [H][W][C] of the input instead (nullptr: the input is complete)
 };
-// op 0: conv2 (the word itself); op 1: conv3 (3x3, stride 2, pad 1: rows whose window ends above s2); op 2: conv4 and op 3: conv5
+// op 0: conv2 (the count itself); op 1: conv3 (3x3, stride 2, pad 1: rows whose window ends above s2); op 2: conv4 and op 3: conv5
 // (3x3, vertical stride 1, pad 1: one row fewer each)
 __host__ __device__ inline int conv_skip_decode(int w, int op) {
     const int s3 = w / 2;
     const int s = op == 0 ? w : s3 - (op - 1);
     return s > 0 ? s : 0;
 }
+// one layer of the compaction (launch_conv_rowmaps)
+struct ConvRowMap {
+    int OH, OW, op;           // output geometry of the layer and its conv_skip_decode op
+    int* map;                 // [NF*OH*OW] (only the first *total entries are meaningful)
+    int* base;                // [NF + 1] scratch: exclusive prefix of the images' computed rows
+    int* total;               // device word
+};
 constexpr int CONV1_ZHDR_WORDS = 64;        // header of conv1's zero-scan scratch: 32 words of zconst, then ...
-constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's position-independent leading rows
+constexpr int CONV1_ROWSKIP_WORD = 32;      // ... the min over the launch's positions of conv2's position-independent leading rows (debug only)
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void tap_decode(const ConvGeom& g, int p, int& kh, int& kw) {
@@ -172,9 +180,12 @@ hipError_t launch_conv1_edge_fix(f16* out_pooled, const f16* edge, long position
 // the 64 per-channel values relu(bias) that conv1 produces over an all-zero patch, as the kernel rounds them (-> const chain)
 hipError_t launch_conv1_zconst(const f16* Wd, float scale, f16* zconst, hipStream_t s);
 size_t conv1_zmask_elems(int nclip, int T);
+const int* conv1_s2_counts(const unsigned* zscratch, int nclip, int T, int pad);     // [nclip*P] per position: conv2's position-independent leading rows
+// compaction maps of the conv layers behind conv1 from the per-position counts s2 (NF positions = images)
+hipError_t launch_conv_rowmaps(const int* s2, int NF, const ConvRowMap* layers, int nlayers, hipStream_t s);
 size_t conv1_edge_elems(long positions);
-// in_rowskip / in_op / const_in as in ConvGeom: input rows below conv_skip_decode(*in_rowskip, in_op) come from the const image
-hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* in_rowskip = nullptr,
+// s2 / in_op / const_in as in ConvGeom: input rows of image n below conv_skip_decode(s2[n], in_op) come from the const image
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* s2 = nullptr,
                                int in_op = 0, const f16* const_in = nullptr);
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
                                 float* x32, f16* x16, hipStream_t s);

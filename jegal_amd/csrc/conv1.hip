@@ -52,8 +52,8 @@ struct Conv1Args {
     const unsigned* zmask;    // [nclip*P] per POSITION: bit rt = tile rt of the position's 5 strips is skipped outright
                               // (conv1_zero_scan_kernel + conv1_skip_mask_kernel); nullptr: no tile is skipped
     const f16* zconst;        // [64] relu(bias) per channel as fp16: the value of every conv1 output whose patch is all zero
-    const int* fill_from;     // nullptr, or the device word conv2 reads its row skip r from (common.h: ConvGeom::rowskip): conv2 then
-                              // reads pooled rows >= 2r only, and the constant fill of the skipped tiles leaves the rows above unwritten
+    int fill_partial;         // 1: conv2 honours the per-position row skip (common.h, ConvGeom::rowmap): it reads pooled rows >= 2 s2 of a
+                              // position only (s2 from the position's own skip mask), and the constant fill leaves the rows above unwritten
     int dbg;              // ablation switch (env JG_CONV1_DBG): 1 = loaders idle, 2 = MFMA waves idle, 4 = no pooling,
                           // 8 = no u8->fp16 conversion / LDS fill (timing experiments only)
 };
@@ -90,6 +90,16 @@ struct C1Regs { u32x3 w[2][5]; };           // two (row, 4-pixel group) items x 
 
 __device__ __forceinline__ f16x8 max8(f16x8 a, f16x8 b) {
     return __builtin_elementwise_max(a, b);            // 4 x v_pk_max_f16
+}
+
+// conv2's position-independent leading output rows of a position from its skip mask: with row tiles 0..L-1 skipped the pooled
+// rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2, no padding) output row oh reads pooled rows
+// 2oh..2oh+4: rows 0..L-3 are what conv2 computes from an all-constant image.  An all-black position still computes its last row.
+__device__ __forceinline__ int conv1_s2_of_mask(unsigned sk) {
+    const int L = __builtin_ctz(~sk);                // sk has 22 bits: L <= 22
+    constexpr int C2_OH = (PH - 5) / 2 + 1;          // conv2 output rows (20)
+    const int rs = L >= 2 ? L - 2 : 0;
+    return rs < C2_OH ? rs : C2_OH - 1;
 }
 
 // DBG: the timeline stamps (JG_CONV1_TL) and the ablation switches (JG_CONV1_DBG) exist only in the <true> instantiation: in the
@@ -146,7 +156,6 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // walks would put an s_waitcnt vmcnt(0) -- hipcc cannot count across the walks' loops -- behind every batch of frame loads.
     const unsigned* skip_tab = reinterpret_cast<const unsigned*>(smem + OFF_SKIP);
     const bool use_skip = a.zmask != nullptr;
-    const int fill_lo = a.fill_from ? 2 * __builtin_amdgcn_readfirstlane(*a.fill_from) : 0;     // first pooled row the fill must write
     auto strip_skip = [&](int k) -> unsigned {
         return use_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip_tab[k]) : 0u;
     };
@@ -383,6 +392,8 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // mapping as part A of pool(): one 16-B store per thread and skipped tile, no LDS, no barrier.
         auto fill_skipped = [&](int strip, unsigned skip) {
             if (!skip) return;
+            // first pooled row the fill must write: conv2 of THIS position reads pooled rows >= 2 s2 only (conv1_s2_of_mask)
+            const int fill_lo = a.fill_partial ? 2 * conv1_s2_of_mask(skip) : 0;
             const int nf = (int)((unsigned)strip / 5u);
             const int j = strip - nf * 5;
             const int pw = 16 * j + ppw;
@@ -671,13 +682,11 @@ __global__ __launch_bounds__(256) void conv1_zero_scan_kernel(const uint8_t* __r
 // when its band is zero in all five; it is SKIPPED when the tile above is all-zero too (or does not exist): both of its pooled
 // rows (2rt-1: carry of the tile above and its own row 0; 2rt: its rows 0..2) are then the constant.  Its own carry is the
 // constant as well, which the tile below -- if that one runs -- takes from cz instead of LDS (pool(), carry_const).
-// It also reduces, over all positions of the launch, how many leading rows of the NEXT layer's output do not depend on the
-// position: with row tiles 0..L-1 skipped the pooled rows 0..2L-2 hold relu(bias) in every column, and conv2 (5x5, stride 2,
-// no padding) output row oh reads pooled rows 2oh..2oh+4: rows 0..L-3 are what conv2 computes from an all-constant image.
-// The conv2 GEMM then computes rows >= L-2 only, and so on down the stack (ConvGeom::rowskip, the const chain of api.hip);
-// *rowskip = min (L-2).
+// It also writes s2[nf], conv2's position-independent leading output rows of the position (conv1_s2_of_mask): the conv2 GEMM
+// computes rows >= s2[nf] of that position only, and so on down the stack (ConvGeom::rowmap, the const chain of api.hip).
+// *rowskip_min = min over the launch (a debug word: jg_debug_conv2_rowskip).
 __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int nclip, int T, int pad, int P, unsigned* __restrict__ skip,
-                                       int* __restrict__ rowskip) {
+                                       int* __restrict__ s2, int* __restrict__ rowskip_min) {
     const int nf = blockIdx.x * blockDim.x + threadIdx.x;
     int rs = 0x7fffffff;
     if (nf < nclip * P) {
@@ -690,22 +699,100 @@ __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int ncli
         }
         const unsigned sk = z & ((z << 1) | 1u);
         skip[nf] = sk;
-        const int L = __builtin_ctz(~sk);                // sk has 22 bits: L <= 22
-        constexpr int C2_OH = (PH - 5) / 2 + 1;          // conv2 output rows (20)
-        rs = L >= 2 ? L - 2 : 0;
-        rs = rs < C2_OH ? rs : C2_OH - 1;                // an all-black position: conv2 still computes its last row
+        rs = conv1_s2_of_mask(sk);
+        s2[nf] = rs;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const int o = __shfl_xor(rs, d, 64);
         rs = o < rs ? o : rs;
     }
-    if ((threadIdx.x & 63) == 0 && rs != 0x7fffffff) atomicMin(rowskip, rs);
+    if ((threadIdx.x & 63) == 0 && rs != 0x7fffffff) atomicMin(rowskip_min, rs);
+}
+
+// ---- compaction maps of the conv layers behind conv1 (common.h: ConvGeom::rowmap, ConvRowMap) ----------------------------------
+// Image (position) img computes rows >= s = conv_skip_decode(s2[img], op) of a layer's OH x OW output.  Step 1, one workgroup:
+// exclusive prefix of the images' computed pixels per layer (base[img], *total).  Step 2, one workgroup per image: its computed
+// pixels (one contiguous run of full indices per layer) go to their compacted place, | s2 << 24.
+struct RowMapArgs {
+    const int* s2;
+    int NF, nl;
+    ConvRowMap L[4];
+};
+__global__ __launch_bounds__(1024) void conv_rowmap_scan_kernel(RowMapArgs a) {
+    __shared__ int part[4][1024];
+    const int tid = threadIdx.x;
+    const int per = (a.NF + 1023) / 1024;                  // consecutive images per thread
+    const int i0 = tid * per, i1 = i0 + per < a.NF ? i0 + per : a.NF;
+    int sum[4] = {0, 0, 0, 0};
+    for (int i = i0; i < i1; ++i) {
+        const int w = a.s2[i];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) sum[l] += (a.L[l].OH - conv_skip_decode(w, a.L[l].op)) * a.L[l].OW;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) part[l][tid] = sum[l];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // Hillis-Steele inclusive scan, the four layers side by side
+        int v[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) v[l] = tid >= d ? part[l][tid - d] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 4; ++l) part[l][tid] += v[l];
+        __syncthreads();
+    }
+    int run[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) run[l] = part[l][tid] - sum[l];
+    for (int i = i0; i < i1; ++i) {
+        const int w = a.s2[i];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (l < a.nl) a.L[l].base[i] = run[l];
+            run[l] += (a.L[l].OH - conv_skip_decode(w, a.L[l].op)) * a.L[l].OW;
+        }
+    }
+    if (tid == 1023) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (l < a.nl) { a.L[l].base[a.NF] = part[l][1023]; *a.L[l].total = part[l][1023]; }
+    }
+}
+// one workgroup per image: its computed pixels of every layer, in order
+__global__ __launch_bounds__(256) void conv_rowmap_fill_kernel(RowMapArgs a) {
+    const int img = blockIdx.x;
+    const int w = a.s2[img];
+    for (int l = 0; l < a.nl; ++l) {
+        const ConvRowMap& R = a.L[l];
+        const int s = conv_skip_decode(w, R.op);
+        const int n = (R.OH - s) * R.OW;                   // computed pixels of this image: full rows s*OW .. OH*OW - 1
+        const int first = img * R.OH * R.OW + s * R.OW;
+        int* dst = R.map + R.base[img];
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = (first + i) | (w << 24);
+    }
 }
 
 // workspace words: header of CONV1_ZHDR_WORDS (zconst: 64 halves = 32 words; word CONV1_ROWSKIP_WORD: constant leading rows of
 // conv2's output) + nclip*T (frame masks) + nclip*(T+2*pad-4) (position skip masks)
-size_t conv1_zmask_elems(int nclip, int T) { return (size_t)CONV1_ZHDR_WORDS + (size_t)nclip * T + (size_t)nclip * (T + 20); }
+// + nclip*(T+2*pad-4) (per-position counts s2); sized for pad <= 12
+size_t conv1_zmask_elems(int nclip, int T) { return (size_t)CONV1_ZHDR_WORDS + (size_t)nclip * T + 2 * (size_t)nclip * (T + 20); }
+const int* conv1_s2_counts(const unsigned* zscratch, int nclip, int T, int pad) {
+    return reinterpret_cast<const int*>(zscratch + CONV1_ZHDR_WORDS + (size_t)nclip * T + (size_t)nclip * (T + 2 * pad - 4));
+}
+
+hipError_t launch_conv_rowmaps(const int* s2, int NF, const ConvRowMap* layers, int nlayers, hipStream_t s) {
+    if (NF <= 0 || nlayers <= 0 || nlayers > 4) return hipErrorInvalidValue;
+    RowMapArgs a;
+    a.s2 = s2; a.NF = NF; a.nl = nlayers;
+    for (int l = 0; l < 4; ++l) {
+        a.L[l] = layers[l < nlayers ? l : nlayers - 1];
+        if ((long)NF * a.L[l].OH * a.L[l].OW >= (1L << 24)) return hipErrorInvalidValue;      // 24-bit row index in the map entries
+    }
+    hipLaunchKernelGGL(conv_rowmap_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(conv_rowmap_fill_kernel, dim3((unsigned)NF), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 // Zero-band scan + per-position skip masks + the zero-patch constant into `zscratch` (conv1_zmask_elems words).
 hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, const f16* Wd, float scale, unsigned* zscratch, hipStream_t s) {
@@ -716,7 +803,7 @@ hipError_t launch_conv1_scan(const uint8_t* src, int nclip, int T, int pad, cons
     f16* zc = reinterpret_cast<f16*>(zscratch);
     hipLaunchKernelGGL(conv1_zero_scan_kernel, dim3((unsigned)(nclip * T)), dim3(256), 0, s, src, fz, Wd, scale * 16777216.0f, zc);
     hipLaunchKernelGGL(conv1_skip_mask_kernel, dim3((unsigned)((nclip * P + 255) / 256)), dim3(256), 0, s, fz, nclip, T, pad, P, sk,
-                       reinterpret_cast<int*>(zscratch) + CONV1_ROWSKIP_WORD);
+                       reinterpret_cast<int*>(sk + (size_t)nclip * P), reinterpret_cast<int*>(zscratch) + CONV1_ROWSKIP_WORD);
     return hipGetLastError();
 }
 
@@ -753,12 +840,12 @@ hipError_t launch_conv1_direct(const uint8_t* src, int nclip, int T, int pad, co
     a.zskip = o.conv1_zero_skip ? 1 : 0;
     a.zmask = nullptr;
     a.zconst = nullptr;
-    a.fill_from = nullptr;
+    a.fill_partial = 0;
     if (num_cu > MAX_WGS) return hipErrorInvalidValue;
     if (a.zskip && zscratch && nclip * T > 0 && (a.nstrips + num_cu - 1) / num_cu + 8 <= MAX_WG_STRIPS) {
         a.zmask = zscratch + CONV1_ZHDR_WORDS + (size_t)nclip * T;
         a.zconst = reinterpret_cast<const f16*>(zscratch);
-        if (!fill_all) a.fill_from = reinterpret_cast<const int*>(zscratch) + CONV1_ROWSKIP_WORD;
+        if (!fill_all) a.fill_partial = 1;
     }
     static unsigned long long* tl = nullptr;
     static const bool want_tl = getenv("JG_CONV1_TL") != nullptr;

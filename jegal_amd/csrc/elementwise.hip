@@ -56,8 +56,8 @@ hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st,
 // ---------------------------------------------------------------------------------------------
 // MaxPool (1,3,3)/(1,2,2), no padding, NHWC fp16, 8 channels per thread (gestsync.py:42-45,74-77).
 __global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out, int N, int H, int W, int C, int OH, int OW,
-                               const int* __restrict__ in_rowskip, int in_op, const f16* __restrict__ const_in) {
-    const int rin = in_rowskip && const_in ? conv_skip_decode(*in_rowskip, in_op) : 0;
+                               const int* __restrict__ s2, int in_op, const f16* __restrict__ const_in) {
+    const bool skip = s2 && const_in;
     const int cv = C / 8;
     const long total = (long)N * OH * OW * cv;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -67,6 +67,7 @@ __global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out
         r /= OW;
         const int oh = r % OH;
         const int n = r / OH;
+        const int rin = skip ? conv_skip_decode(s2[n], in_op) : 0;      // image n's producer left its first rin rows to the const image
         f16x8 m;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -84,12 +85,12 @@ __global__ void maxpool_kernel(const f16* __restrict__ in, f16* __restrict__ out
     }
 }
 
-hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* in_rowskip, int in_op,
+hipError_t launch_maxpool3x3s2(const f16* in, f16* out, int N, int H, int W, int C, hipStream_t s, const int* s2, int in_op,
                                const f16* const_in) {
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
     const long total = (long)N * OH * OW * (C / 8);
     const int grid = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, N, H, W, C, OH, OW, in_rowskip, in_op, const_in);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid), dim3(256), 0, s, in, out, N, H, W, C, OH, OW, s2, in_op, const_in);
     return hipGetLastError();
 }
 

@@ -207,8 +207,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //   weights -- 1.5x fewer L2->LDS bytes per FLOP, which is what bounds the 256x128 kernel once the lo MFMAs are gone.
 // LNF: row-wide 128x512 tile with the residual add and the LayerNorm in the epilogue (tiled fp16 + 8-bit token stream).
 // SPR: plain GEMM -- the next k-tile's DMA pieces are spread over the MFMA schedule (K <= 1024 instances);
-//      CONV -- the loader can read the producer's left-out leading rows from a const image (ConvGeom::in_rowskip / const_in).
-// Every CONV instance honours ConvGeom::rowskip on its output side (compacted row index, row_full()).
+//      CONV -- the loader can read the producer's left-out leading rows from a const image (ConvGeom::in_op / const_in).
+// Every CONV instance honours ConvGeom::rowmap on its output side (compacted row index, row_full()).
 template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
@@ -227,45 +227,30 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     const int fsw = (frow >> 1) & 7;
     const int lrow = lane >> 3, pc = lane & 7;
 
-    // CONV with ConvGeom::rowskip: the first `rsk` output rows of every image are not computed.  The kernel then runs over the
-    // compacted row index m' (images of (OH - rsk) x OW pixels); Mrows replaces a.M, and row_full() maps m' to the row of the
-    // full output the epilogue writes.  m' < 2^24 (checked by the launcher): the image index comes from a float reciprocal.
-    int Mrows = a.M, rsk = 0, perc = 1;
-    long rsk_rows = 0;
-    float inv_perc = 0.f;
+    // CONV with ConvGeom::rowmap: the kernel runs over the COMPACTED rows m' of the launch -- per image the output rows that
+    // depend on the position (common.h) -- and rowmap[m'] gives the full output row (the pixel to compute, the row the epilogue
+    // stores to) and the image's count s2 in the top byte.  Mrows replaces a.M.
+    int Mrows = a.M;
+    const int* rmap = nullptr;
+    const float inv_per = CONV ? 1.0f / (float)(a.g.OH * a.g.OW) : 0.f, inv_ow = CONV ? 1.0f / (float)a.g.OW : 0.f;
     if constexpr (CONV) {
-        if (a.g.rowskip) {
-            rsk = conv_skip_decode(__builtin_amdgcn_readfirstlane(*a.g.rowskip), a.g.rowskip_op);
-            rsk = rsk > 0 && rsk < a.g.OH ? rsk : 0;
-            if (rsk) {
-                const int nimg = a.M / (a.g.OH * a.g.OW);
-                perc = (a.g.OH - rsk) * a.g.OW;
-                Mrows = nimg * perc;
-                inv_perc = 1.0f / (float)perc;
-                rsk_rows = (long)rsk * a.g.OW;
-                total_tiles = ((Mrows + BM - 1) / BM) * n_tiles;
-            }
+        if (a.g.rowmap) {
+            rmap = a.g.rowmap;
+            Mrows = __builtin_amdgcn_readfirstlane(*a.g.rows_total);
+            total_tiles = ((Mrows + BM - 1) / BM) * n_tiles;
         }
     }
-    // ConvGeom::in_rowskip / const_in (conv instances with SPR, which has no other meaning for CONV: launch_glds picks them when
-    // the pointer is set): input rows 0..rin-1 of every image were left out by the producer (ConvGeom::rowskip) because they do
-    // not depend on the position; the loader reads them from the const image of the input instead (same pixel, other base).
+    // ConvGeom::in_op / const_in (conv instances with SPR, which has no other meaning for CONV: launch_glds picks them when
+    // const_in is set): input rows 0..rin-1 of an image were left out by the producer because they do not depend on the
+    // position; the loader reads them from the const image of the input instead (same pixel, other base).  rin =
+    // conv_skip_decode(s2[img], in_op) is per row (it rides in the low byte of xpix).
     // Its own instances: the compare + select per LDS-DMA piece cost the 256x256 conv kernel 5 % (conv4 / conv5: 580 -> 610 us)
     // when it was compiled into all of them.
     constexpr bool ROWCONST = CONV && SPR;
-    int rin = 0;
-    if constexpr (ROWCONST) {
-        if (a.g.in_rowskip && a.g.const_in) {
-            rin = conv_skip_decode(__builtin_amdgcn_readfirstlane(*a.g.in_rowskip), a.g.in_op);
-            rin = rin > 0 ? rin : 0;
-        }
-    }
+    const bool rowconst = ROWCONST && rmap && a.g.const_in;
     auto row_full = [&](int m) -> long {
-        if (!CONV || rsk == 0) return m;
-        int img = (int)((float)m * inv_perc);
-        const int base = img * perc;
-        img += base > m ? -1 : (base + perc <= m ? 1 : 0);
-        return (long)m + (long)(img + 1) * rsk_rows;
+        if (!CONV || !rmap) return m;
+        return rmap[m] & 0xffffff;
     };
 
     // Persistent: one workgroup per CU walks rounds of G tiles.  Within a round the workgroups of one
@@ -289,8 +274,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     // of ONE tap, so (kh, kw, c0) are wave-uniform and simply advance with the k-tiles (stage() is always called for
     // kt = 0, 1, 2, ... of a tile); per lane only the pointer to its (pixel, chunk) at tap (0,0) -- possibly outside
     // the image for padded layers, dereferenced only when the tap lands inside -- and the pixel coordinates remain.
-    // Register budget (the 128x512 and 512x128 instances sit at the 256-VGPR limit): the pixel coordinates of a conv row
-    // share one register (ih << 16 | iw & 0xffff), and the WI weight-row pointers are two base pointers (even / odd
+    // Register budget (the 128x512 and 512x128 instances sit at the 256-VGPR limit): the pixel coordinates of a conv row and
+    // its image's const-row count share one register (ih << 20 | (iw & 0xfff) << 8 | rin), and the WI weight-row pointers are two base pointers (even / odd
     // 8-row piece: the swizzled chunk depends on the piece's parity only) plus a wave-uniform multiple of 16 rows.
     const f16* xsrc[XI];
     const f16* xalt[ROWCONST ? XI : 1];          // the same pixel in the const image of the input (ROWCONST)
@@ -311,12 +296,26 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             int m = m0 + row;
             m = m < Mrows ? m : Mrows - 1;
             if (CONV) {
-                const int per = rsk ? perc : a.g.OH * a.g.OW;
-                const int img = m / per, rem = m - img * per;
-                const int ohc = rem / a.g.OW, ow = rem - ohc * a.g.OW;
-                const int oh = ohc + rsk;
+                int s2 = 0;
+                if (rmap) {
+                    const int e = rmap[m];
+                    m = e & 0xffffff;
+                    s2 = (int)((unsigned)e >> 24);
+                }
+                // m < 2^24 (launch_gemm): quotients from float reciprocals with a +-1 fix-up instead of two integer divisions
+                // (8 pieces x 2 divisions per tile and lane, and their temporaries on top of 128 live accumulators)
+                const int per = a.g.OH * a.g.OW;
+                int img = (int)((float)m * inv_per);
+                int rem = m - img * per;
+                img += rem < 0 ? -1 : (rem >= per ? 1 : 0);
+                rem += rem < 0 ? per : (rem >= per ? -per : 0);
+                int oh = (int)((float)rem * inv_ow);
+                int ow = rem - oh * a.g.OW;
+                oh += ow < 0 ? -1 : (ow >= a.g.OW ? 1 : 0);
+                ow += ow < 0 ? a.g.OW : (ow >= a.g.OW ? -a.g.OW : 0);
                 const int ih = oh * a.g.SH - a.g.PH, iw = ow * a.g.SW - a.g.PW;
-                xpix[i] = (ih << 16) | (iw & 0xffff);
+                const int rin = rowconst ? conv_skip_decode(s2, a.g.in_op) : 0;
+                xpix[i] = (ih << 20) | ((iw & 0xfff) << 8) | rin;      // |ih|, |iw| < 2048 (checked by launch_gemm), rin <= 19
                 xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
                 if constexpr (ROWCONST) xalt[i] = a.g.const_in + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
             } else {
@@ -366,10 +365,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             const int i = p;
             const f16* src;
             if (CONV) {
-                const int ih = (xpix[i] >> 16) + stkh, iw = (int)(short)(xpix[i] & 0xffff) + stkw;
+                const int ih = (xpix[i] >> 20) + stkh, iw = ((xpix[i] << 12) >> 20) + stkw;
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
-                if (ROWCONST && ok && ih < rin) src = xalt[i] + stapoff;
+                if (ROWCONST && ok && ih < (xpix[i] & 0xff)) src = xalt[i] + stapoff;
             } else {
                 src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }
@@ -397,6 +396,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     };
 
     const int nk = (a.K + 63) / 64;
+    // conv launches carry no residual (launch_gemm rejects them): the conv instances are compiled without that path -- the
+    // hoisted reciprocal of its `m % res_mod` alone cost the 512x128 instance a spilled register
+    const float* const ares = CONV ? nullptr : a.res;
 
     int round = 0;
     int bid = tile_of(0);
@@ -507,13 +509,13 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int p = 0; p < NPIECE; ++p) stage_piece(p, (kt + 1) & 1);
             }
-            if (PREFETCH_RES && kt == nk - 1 && interior && a.res) {
+            if (PREFETCH_RES && kt == nk - 1 && interior && ares) {
                 // residual prefetch: issued under the last k-tile's MFMAs, consumed in the epilogue
 #pragma unroll
                 for (int j = 0; j < (PREFETCH_RES ? MI : 1); ++j) {
                     const int m = mb + j * 16;
                     const int rr = a.res_mod ? (m % a.res_mod) : m;
-                    const float* rp = a.res + (long)rr * a.ldr + nb;
+                    const float* rp = ares + (long)rr * a.ldr + nb;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rs[i][j] = *reinterpret_cast<const f32x4*>(rp + i * 16);
                 }
@@ -562,12 +564,39 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
 
         mark();     // 1: k loop done
+        // fp16-only outputs (qkv, linear1, the conv layers) leave through the row-transposing epilogue below
+        constexpr int TP16 = 144;                        // row pitch: 16-B aligned, 36 banks -> conflict-free b64 writes
+        constexpr bool ROWS_OK = STAGE / 8 >= 16 * TP16;
+        const bool rows16 = ROWS_OK && interior && a.out16 && !a.out32 && !ares && (a.ldc & 7) == 0;
+        const int orow_m = cm0 + wm * (16 * MI) + (lane >> 3);
+        // ConvGeom::rowmap: the full output rows of this wave's 16*MI tile rows (both store paths below stay inside them) go
+        // through a per-wave table in LDS -- 1-2 loads per lane, in front of the next tile's setup and OLDER than its first DMA,
+        // so nothing in the epilogue waits for that DMA.  (Sixteen row indices per lane in registers spilled the 512x128 and
+        // the ROWCONST instances, and so did two values kept live across setup().)  The table sits behind
+        // the transposing epilogue's scratch in LDS stage 1, which is idle until the next tile's k-tile 1 is staged.
+        constexpr int WROWS = 16 * MI;
+        // (per-lane table addresses are recomputed from a laundered lane id per tile: hoisted out of the persistent loop as
+        // invariants they cost the 512x128 instance four spilled registers)
+        int lane_t = lane;
+        if constexpr (CONV) asm volatile("" : "+v"(lane_t));
+        int* rtab = reinterpret_cast<int*>(smem + STAGE + 8 * (16 * TP16)) + wave * 128;
+        const bool use_rtab = CONV && rmap && interior;
+        if constexpr (CONV) {
+            if (use_rtab) {
+                const int wrow0 = cm0 + wm * WROWS;
+                if (WROWS >= 64 || lane_t < WROWS) rtab[lane_t] = rmap[wrow0 + lane_t] & 0xffffff;
+                if (WROWS > 64) rtab[64 + lane_t] = rmap[wrow0 + 64 + lane_t] & 0xffffff;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // next tile: issue its first k-tile now, BEFORE the epilogue's stores (LNF: inside its epilogue, see there)
         const int nbid = tile_of(++round);
-        if (nbid >= 0) {
-            setup(nbid);
-            if (!LNF) stage(0, 0);
-        }
+        if (nbid >= 0) setup(nbid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nbid >= 0 && !LNF) stage(0, 0);
         __builtin_amdgcn_sched_barrier(0);       // keep the DMA older than the stores (the counted wait relies on it)
         if (!LNF) mark();     // 2: next tile's first DMA issued (LNF: statistics done, see below)
 
@@ -678,9 +707,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         // whole k loop at K = 512 (tools/store_pattern.hip, tools/gemm_timeline.py).  The scratch is this wave's
         // slice of LDS stage 1, idle until the next tile's k-tile 1 is staged (after the barrier at the loop top);
         // a wave's LDS instructions execute in order, so consecutive 16-row blocks reuse the same 2.3 KB.
-        constexpr int TP16 = 144;                        // row pitch: 16-B aligned, 36 banks -> conflict-free b64 writes
-        constexpr bool ROWS_OK = STAGE / 8 >= 16 * TP16;
-        const bool rows16 = ROWS_OK && interior && a.out16 && !a.out32 && !a.res && (a.ldc & 7) == 0;
         if (rows16) {
             char* tsc = smem + STAGE + wave * (16 * TP16);
             f32x4 sc[4], bi[4];
@@ -697,7 +723,6 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
-            const int orow_m = cm0 + wm * (16 * MI) + (lane >> 3);
             f16* ocol = a.out16 + cn0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
@@ -716,7 +741,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
-                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(ocol + row_full(orow_m + j * 16 + h2 * 8) * a.ldc));
+                    const long orow = use_rtab ? rtab[j * 16 + h2 * 8 + (lane_t >> 3)] : orow_m + j * 16 + h2 * 8;
+                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(ocol + orow * a.ldc));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -739,15 +765,15 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                const long mo = row_full(mb + j * 16) * a.ldc + nb;
+                const long mo = (use_rtab ? (long)rtab[j * 16 + (lane_t & 15)] : (long)(mb + j * 16)) * a.ldc + nb;
                 f32x4 rj[4];
                 if (!PREFETCH_RES) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) rj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.res) {
+                    if (ares) {
                         const int m = mb + j * 16;
                         const int rr = a.res_mod ? (m % a.res_mod) : m;
-                        const float* rp = a.res + (long)rr * a.ldr + nb;
+                        const float* rp = ares + (long)rr * a.ldr + nb;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) rj[i] = *reinterpret_cast<const f32x4*>(rp + i * 16);
                     }
@@ -779,9 +805,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                     if (m >= Mrows) continue;
                     const long mf = row_full(m);
                     f32x4 v = acc[i][j] * sc + bi;
-                    if (a.res) {
+                    if (ares) {
                         const int rr = a.res_mod ? (m % a.res_mod) : m;
-                        v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
+                        v += *reinterpret_cast<const f32x4*>(ares + (long)rr * a.ldr + n);
                     }
                     if (a.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -913,7 +939,7 @@ static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_
     const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     const long tiles_big = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);        // 256x256 tiles: fewer than CUs -> under-filled
     if constexpr (CONV) {
-        if (a.g.in_rowskip && a.g.const_in) {   // consumer of a row-skipping producer: the instances whose loader can read the const image
+        if (a.g.rowmap && a.g.const_in) {   // consumer of a row-skipping producer: the instances whose loader can read the const image
             if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, true, 2, 4, 2, true>(a, o, s);
             if constexpr (!W2) {
                 if (o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0) return launch_glds_cfg<false, true, 8, 2, 4, true>(a, o, s);
@@ -955,8 +981,11 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStr
     const bool narrow = a.N <= 64;
     if (a.a_tiled && (conv || narrow || !o.gemm_glds || a.K != 512 || a.M < 128 || a.N % 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
     if (conv) {
+        if (a.res) return hipErrorInvalidValue;          // the conv instances are compiled without the residual path
         if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
-        if (o.gemm_glds && a.M >= 256 && a.g.C % 64 == 0 && a.N % 128 == 0) return w2 ? launch_glds<true, true>(a, o, s) : launch_glds<false, true>(a, o, s);
+        const bool coords_ok = a.g.H + a.g.PH < 2048 && a.g.W + a.g.PW < 2048 && a.M < (1 << 24);      // packed pixel coordinates / rowmap entries
+        if (o.gemm_glds && a.M >= 256 && a.g.C % 64 == 0 && a.N % 128 == 0 && coords_ok) return w2 ? launch_glds<true, true>(a, o, s) : launch_glds<false, true>(a, o, s);
+        if (a.g.rowmap) return hipErrorInvalidValue;          // only the LDS-DMA kernel knows the compaction
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);
     }
     if (narrow) return w2 ? launch_variant<4, 1, false, true>(a, s) : launch_variant<4, 1, false, false>(a, s);

@@ -176,16 +176,28 @@ def xlmr_inputs(seed, batch, length, vocab=1000):
 
 # --------------------------------------------------------------------------- inputs
 
-def synth_frames(seed, n_clips, n_frames, height=270, width=480, mask_rows=110):
-    """uint8 (B,T,H,W,3) clips, rows [0,mask_rows) zeroed like the face-mask rectangle
-    of inference_embs.py:264.  A low-frequency pattern is mixed
-    with noise so temporal neighbours differ but are correlated, as in video."""
+def synth_frames(seed, n_clips, n_frames, height=270, width=480, mask_rows=110, mask_jitter=None):
+    """uint8 (B,T,H,W,3) uniform-noise clips, rows [0,mask_rows) zeroed like the face-mask rectangle of
+    inference_embs.py:264.  mask_jitter = (lo, hi): the mask height is drawn PER FRAME from lo..hi
+    instead (the reference blanks rows 0..y2+15 with y2 following the chin, inference_embs.py:264-270); the pixels below
+    the mask are the same as without jitter."""
     rng = np.random.default_rng(seed)
     out = np.empty((n_clips, n_frames, height, width, 3), np.uint8)
     for b in range(n_clips):
         out[b] = rng.integers(0, 256, (n_frames, height, width, 3), dtype=np.uint8)
-    out[:, :, :mask_rows] = 0
+    if mask_jitter is None:
+        out[:, :, :mask_rows] = 0
+    else:
+        hts = mask_heights(seed, n_clips, n_frames, *mask_jitter)
+        for b in range(n_clips):
+            for t in range(n_frames):
+                out[b, t, :hts[b, t]] = 0
     return out
+
+
+def mask_heights(seed, n_clips, n_frames, lo, hi):
+    """Per-frame mask heights of synth_frames(..., mask_jitter=(lo, hi)), i.i.d. uniform in lo..hi (harsher than video)."""
+    return np.random.default_rng([seed, 0x6A17]).integers(lo, hi + 1, (n_clips, n_frames))
 
 
 def synth_mel(seed, n_clips, n_mel_frames):

@@ -185,37 +185,90 @@ def test_conv1_zero_band_skip_is_bit_identical(engine, models):
     assert rel(out.float(), alt.float()) < 3e-4
 
 
+def _expected_conv_rows(zero_rows, pad=4):
+    """numpy restatement of the zero-band scan: zero_rows (B,T) = number of leading all-zero rows of every frame -> per position
+    s2 (conv1.hip, conv1_s2_of_mask) -> the output pixels conv2 .. conv5 compute (common.h, conv_skip_decode)."""
+    B, T = zero_rows.shape
+    P = T + 2 * pad - 4
+    bands = np.zeros((B, T), np.int64)                      # leading all-zero 16-row bands (band rt = rows 12 rt .. 12 rt + 15)
+    for rt in range(22):
+        ok = (np.minimum(12 * rt + 16, 270) <= zero_rows) & (bands == rt)
+        bands = bands + ok
+    s2 = np.zeros((B, P), np.int64)
+    for p in range(P):
+        fr = np.clip(p + np.arange(5) - pad, 0, T - 1)
+        nb = bands[:, fr].min(axis=1)                       # bands zero in all five frames
+        # tile rt is skipped when bands rt and rt-1 are zero -> L = nb (for a prefix of zero bands), s2 = clamp(L - 2, 0, 19)
+        s2[:, p] = np.clip(nb - 2, 0, 19)
+    s3 = s2 // 2
+    rows = [((20 - s2) * 37).sum(), ((10 - s3) * 19).sum(), ((10 - np.maximum(s3 - 1, 0)) * 10).sum(), ((10 - np.maximum(s3 - 2, 0)) * 10).sum()]
+    full = [B * P * 740, B * P * 190, B * P * 100, B * P * 100]
+    return [int(r) for r in rows], full, int(s2.min())
+
+
+def _run_row_skip_case(engine, clips, zero_rows):
+    frames = torch.from_numpy(clips).cuda()
+    engine.set_option("ws_poison", 1)           # rows that the skips leave unwritten are NaN: reading one would show
+    engine.set_option("dual_stream", 0)         # one conv stack per call: jg_debug_conv_rows reports the last one
+    try:
+        out = engine.extract_gesture(frames).clone()
+        got_min = engine.debug_conv2_rowskip()
+        got_rows, got_full = engine.debug_conv_rows()
+    finally:
+        engine.set_option("ws_poison", 0)
+        engine.set_option("dual_stream", 1)
+    assert torch.isfinite(out).all()
+    engine.set_option("conv2_row_skip", 0)
+    try:
+        ref = engine.extract_gesture(frames)
+        assert engine.debug_conv2_rowskip() == 0 and engine.debug_conv_rows()[0] == [0, 0, 0, 0]
+    finally:
+        engine.set_option("conv2_row_skip", 1)
+    want_rows, want_full, want_min = _expected_conv_rows(zero_rows)
+    assert (got_rows, got_full, got_min) == (want_rows, want_full, want_min)
+    assert torch.equal(out, ref)
+    return out
+
+
 def test_conv2_row_skip_follows_the_zero_bands(engine, models):
-    """Behind conv1's zero-band skip the leading rows of conv2 / conv3 / conv4 do not depend on the position: the layers leave
-    them out and their consumers read them from the const chain built at weight load.  conv2's count comes from the zero-band
-    scan as the minimum over all positions of the launch: rows 0..109 masked -> bands 0..7 zero -> tiles 0..7 skipped (L = 8)
-    -> L - 2 = 6 rows (conv3: 3, conv4: 2); it must follow the SMALLEST mask of the batch, be 0 for unmasked input, and never
-    change a bit of the embeddings.  The workspace is poisoned with NaN patterns: reading a left-out row would show."""
+    """Behind conv1's zero-band skip the leading rows of conv2 .. conv5 of a position do not depend on the position: the layers
+    leave them out and their consumers read them from the const chain built at weight load.  The count is PER POSITION (round 3;
+    it used to be the minimum over the launch): rows 0..109 masked -> bands 0..7 zero -> tiles 0..7 skipped (L = 8) -> conv2
+    skips L - 2 = 6 rows (conv3: 3, conv4: 2, conv5: 1) of that position.  A clip with a smaller mask, or ONE unmasked byte in
+    one frame, only costs the positions that see it; unmasked input skips nothing, black clips all but the last row; and no
+    case changes a bit of the embeddings.  The workspace is poisoned with NaN patterns: reading a left-out row would show."""
     rng = np.random.default_rng(99)
-    T = 30
-    cases = []
-    a = rng.integers(1, 256, (2, T, 270, 480, 3), dtype=np.uint8); a[:, :, :110] = 0; cases.append((a, 6))
-    b = a.copy(); b[1, :, :110] = rng.integers(1, 256, (T, 110, 480, 3), dtype=np.uint8); b[1, :, :64] = 0; cases.append((b, 3))  # bands 0..4 -> L = 5
-    c = a.copy(); c[0, 17, 3, 100, 1] = 9; cases.append((c, 0))              # one byte in one frame of one clip: that position has L = 0
-    d = rng.integers(1, 256, (2, T, 270, 480, 3), dtype=np.uint8); cases.append((d, 0))
-    e = np.zeros((2, T, 270, 480, 3), dtype=np.uint8); cases.append((e, 19))                # black clips: every row is the constant row
-    for clips, want in cases:
-        frames = torch.from_numpy(clips).cuda()
-        engine.set_option("ws_poison", 1)           # rows that the skips leave unwritten are NaN: reading one would show
-        try:
-            out = engine.extract_gesture(frames).clone()
-        finally:
-            engine.set_option("ws_poison", 0)
-        assert torch.isfinite(out).all()
-        got = engine.debug_conv2_rowskip()
-        engine.set_option("conv2_row_skip", 0)
-        try:
-            ref = engine.extract_gesture(frames)
-            assert engine.debug_conv2_rowskip() == 0
-        finally:
-            engine.set_option("conv2_row_skip", 1)
-        assert got == want, (got, want)
-        assert torch.equal(out, ref)
+    B, T = 2, 30
+    a = rng.integers(1, 256, (B, T, 270, 480, 3), dtype=np.uint8); a[:, :, :110] = 0
+    za = np.full((B, T), 110)
+    _run_row_skip_case(engine, a, za)
+    b = a.copy(); b[1, :, :110] = rng.integers(1, 256, (T, 110, 480, 3), dtype=np.uint8); b[1, :, :64] = 0      # bands 0..4 -> L = 5
+    zb = za.copy(); zb[1] = 64
+    _run_row_skip_case(engine, b, zb)
+    c = a.copy(); c[0, 17, 3, 100, 1] = 9              # one byte in one frame of one clip: the five positions that read it have L = 0
+    zc = za.copy(); zc[0, 17] = 3
+    _run_row_skip_case(engine, c, zc)
+    d = rng.integers(1, 256, (B, T, 270, 480, 3), dtype=np.uint8)
+    _run_row_skip_case(engine, d, np.zeros((B, T), np.int64))
+    e = np.zeros((B, T, 270, 480, 3), dtype=np.uint8)   # black clips: every row is the constant row
+    _run_row_skip_case(engine, e, np.full((B, T), 270))
+
+
+def test_row_skip_with_per_frame_mask_heights(engine, models):
+    """The reference blanks rows 0..y2+15 PER FRAME (inference_embs.py:264-270): y2 follows the chin.  Mask heights drawn per
+    frame from 80..140: every position skips what ITS five frames allow (bit-identical to computing everything), and the
+    computed-row counts match the numpy restatement of the scan."""
+    rng = np.random.default_rng(123)
+    B, T = 3, 40
+    clips = rng.integers(1, 256, (B, T, 270, 480, 3), dtype=np.uint8)
+    zr = rng.integers(80, 141, (B, T))
+    for b in range(B):
+        for t in range(T):
+            clips[b, t, :zr[b, t]] = 0
+    _run_row_skip_case(engine, clips, zr)
+    rows, full, _ = _expected_conv_rows(zr)
+    print("computed / full rows conv2..conv5:", [f"{r / f:.3f}" for r, f in zip(rows, full)])
+    assert rows[0] < 0.85 * full[0]                     # the jittered masks still skip a good part of conv2
 
 
 def test_dual_stream_lanes_are_bit_identical_and_stream_ordered(engine, models):
