@@ -431,6 +431,24 @@ def main():
                     got += emb.shape[0]
                 extras["pcie_clips_per_s"] = got / (time.perf_counter() - t0)
                 del st
+                # the same with only the rows below each clip's mask crossing the link (GestureStreamer(masked=True))
+                st = GestureStreamer(eng, args.clips, FRAMES, masked=True)
+                for s_ in range(2):
+                    for b in range(args.clips):
+                        st.packer[s_].add(frames_host[b], 110)
+                for _ in st.run_filled(lambda pk, k: args.clips if k < 2 else 0):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                got, emb_m = 0, None
+                for _, emb in st.run_filled(lambda pk, k: args.clips if k < nb else 0):
+                    got += emb.shape[0]
+                    emb_m = emb
+                extras["pcie_masked_clips_per_s"] = got / (time.perf_counter() - t0)
+                extras["pcie_masked_bytes"] = st.packer[0].used
+                eng.extract_gesture(frames, out)
+                assert np.array_equal(emb_m, out.cpu().numpy()), "masked upload differs from the resident path"
+                del st
     jdist.barrier()
 
     if rank == 0:
@@ -519,6 +537,11 @@ def main():
             if "pcie_clips_per_s" in extras:
                 res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",
                                          "what": "host-resident clips -> pinned buffers -> H2D under compute -> embeddings back on the host (GestureStreamer); never `value`"}
+            if "pcie_masked_clips_per_s" in extras:
+                res["pcie_inclusive"]["masked_upload"] = {
+                    "value": extras["pcie_masked_clips_per_s"], "unit": "clips/s", "bytes_per_batch": extras["pcie_masked_bytes"],
+                    "bytes_per_batch_dense": args.clips * FRAMES * 270 * 480 * 3, "equals_resident_path": True,
+                    "what": "only the rows below each clip's face mask cross the link (GestureStreamer(masked=True)), jg_unpack_masked rebuilds the batch on the upload stream"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(frames_host[:2])
         else:

@@ -130,6 +130,13 @@ int jg_gestsync_windows(jg_handle* h, const float* x, int N, float* out, float* 
  * (cv2 absent).  The keypoints themselves stay on the host (mediapipe). */
 int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const int32_t* mask_y, uint8_t* dst);
 
+/* Masked crops in fewer bytes (the host link, not the GPU, bounds a streamed extraction: DESIGN.md section 7): the reference blanks
+ * rows 0..y2+15 of every crop (inference_embs.py:264-270), so a producer ships only the rows BELOW each frame's mask.
+ * packed: those rows of all frames back to back (device); row0 (n_frames) int32 device: first kept row of each frame (0..270);
+ * offsets (n_frames) int64 device: byte offset of that row in `packed` (multiples of 16) -> dst (n_frames,270,480,3) uint8 with
+ * the rows above row0 zero: exactly the crop load_rgb_masked_frames returns, ready for jg_gestsync_clip / jg_extract_gesture. */
+int jg_unpack_masked(jg_handle* h, const uint8_t* packed, const int32_t* row0, const int64_t* offsets, int n_frames, uint8_t* dst);
+
 /* ---- JEGAL (models/jegal.py) ---------------------------------------------------------------- */
 /* forward_gestures (jegal.py:78-92) [+ proj_op_align_gesture, jegal.py:381 when align != 0]:
  * feats (B,T,1024) fp32, mask (B,T) fp32 (1 valid / 0 pad) or NULL -> out (B,T,512) fp32. */

@@ -43,6 +43,7 @@ _SIGS = {
     "jg_audio_len": [_I],
     "jg_logmel": [_P, _P, _I, _I, _P, _P],
     "jg_mask_resize": [_P, _P, _I, _I, _I, _P, _P],
+    "jg_unpack_masked": [_P, _P, _P, _P, _I, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
     "jg_xlmr_encode": [_P, _P, _P, _I, _I, _P],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
@@ -323,6 +324,16 @@ class Engine:
         out = torch.empty((T, 270, 480, 3), dtype=torch.uint8, device=self.device)
         self._ck(self.lib.jg_mask_resize(self.h, _ptr(frames_u8), T, H, W, _ptr(my), _ptr(out)))
         return out
+
+    def unpack_masked(self, packed, row0, offsets, dst):
+        """packed uint8 (bytes,) / row0 int32 (F,) / offsets int64 (F,) device tensors -> dst (F,270,480,3) uint8 (written in place)."""
+        self._bind_stream()
+        F = row0.numel()
+        if (packed.dtype != torch.uint8 or row0.dtype != torch.int32 or offsets.dtype != torch.int64 or dst.dtype != torch.uint8
+                or offsets.numel() != F or dst.numel() != F * 270 * 480 * 3 or not dst.is_contiguous()):
+            raise ValueError("unpack_masked: packed uint8, row0 int32 (F), offsets int64 (F), dst uint8 (F,270,480,3)")
+        self._ck(self.lib.jg_unpack_masked(self.h, _ptr(packed), _ptr(row0), _ptr(offsets), F, _ptr(dst)))
+        return dst
 
     def logmel(self, wav, mel_basis):
         """wav (B,n) fp32 (int16 scale) -> log-mel (B, n//160, 80)."""

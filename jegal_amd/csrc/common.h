@@ -103,39 +103,37 @@ struct GemmArgs {
 // ---- tiled token stream (N = 512 columns, row tiles of 128) -----------------------------------------------------
 // The residual stream of the fused transformer is kept as fp16 + an 8-bit correction instead of fp32 (3 instead of
 // 4 bytes per element to read, 3 instead of 6 to write next to the fp16 copy the next GEMM needs anyway):
-//   x  =  x16 + (b - 128) * ulp(x16)/256,   b = sat_u8(rne(128 + (x - x16) * 256/ulp(x16)))  (one byte, biased)
-// (b - 128 in [-128, 127]; +128 saturates to 127: one unit of error on an exact +1/2 ulp tie)
-// i.e. 8 more mantissa bits than fp16 (relative error <= 2^-19 per LayerNorm output, 12 of them per forward pass;
-// the embedding tolerance is 1e-3).  Both planes are stored in the MFMA fragment order of the 128x512 LN kernel:
+//   x  =  x16 + c * 2^-13,   c = e4m3( clamp((x - x16) * 2^13, +-448) )   (one OCP fp8 byte, v_cvt_pk_fp8_f32 / v_cvt_pk_f32_fp8)
+// |x - x16| <= ulp(x16)/2 and e4m3 keeps 4 significant bits of it: relative error <= 2^-16 per LayerNorm output (rms ~ 5e-6;
+// 12 of them per forward pass; the embedding tolerance is 1e-3, the path measures 6e-4 with or without it).  The scale 2^13
+// keeps c normal for |x| between 2^-4 and 128 (below: the absolute error is < 2^-23; above: c saturates and the element
+// degrades towards plain fp16).  Round 2 stored round((x - x16) * 256/ulp(x16)) as a biased byte (2^-19): three more bits
+// that the error budget never saw, for 17 VALU instructions per element in the LayerNorm epilogue instead of 5.
+// Both planes are stored in the MFMA fragment order of the 128x512 LN kernel:
 //   x16t element (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + ((n&63)>>4)*256 + (m&15)*16 + (n&15),  R = m>>7
 //        (a wave's 8-byte accesses of one (j, i) block are one contiguous 512 B; a 64-wide k-tile of a 128-row
 //         panel is one contiguous 16 KB -> the consumer GEMMs' LDS-DMA reads it with a_tiled addressing)
 //   d8t  byte    (m, n): R*65536 + (n>>6)*8192 + ((m&127)>>4)*1024 + lane*16 + ((n&63)>>4)*4 + (n&3),
 //        lane = ((n&15)>>2)*16 + (m&15)   (one 16-byte access per lane and 16-row block)
 #ifdef __HIPCC__
-// ulp(h)/256 = 2^(E-33) with E = max(exponent field of h, 1): the exponent bits of h alone are the fp16 number 2^(E-15), whose
-// conversion to fp32 is exact -- no shifts on the exponent field.  b: the stored byte (0..255).
-__device__ __forceinline__ float res_pow(f16 h) {                 // 2^(E-15)
-    unsigned short m = __builtin_bit_cast(unsigned short, h) & 0x7C00u;
-    m = m > 0x0400u ? m : (unsigned short)0x0400u;
-    return (float)__builtin_bit_cast(f16, m);
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr float RES_SCALE = 8192.f, RES_INV_SCALE = 1.220703125e-4f;      // 2^13, 2^-13
+// h01 / h23: two packed fp16 pairs (elements 0,1 and 2,3), dw: their four corrections
+__device__ __forceinline__ f32x4 res_dec4(unsigned h01, unsigned h23, unsigned dw) {
+    const f32x2_t c01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)dw, false), c23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)dw, true);
+    const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
+    return f32x4{__builtin_fmaf(c01.x, RES_INV_SCALE, (float)a.x), __builtin_fmaf(c01.y, RES_INV_SCALE, (float)a.y),
+                 __builtin_fmaf(c23.x, RES_INV_SCALE, (float)b.x), __builtin_fmaf(c23.y, RES_INV_SCALE, (float)b.y)};
 }
-__device__ __forceinline__ float res_dec(f16 h, unsigned b) {
-    const float u = res_pow(h) * 3.814697265625e-06f;             // 2^-18  ->  2^(E-33)
-    return __builtin_fmaf((float)b, u, __builtin_fmaf(-128.f, u, (float)h));       // exact: 19 significant bits
-}
-// four corrections packed into one dword: v_cvt_pk_u8_f32 rounds to nearest even, saturates to 0..255 and inserts the byte
+// four corrections packed into one dword
 __device__ __forceinline__ unsigned res_enc4(float y0, float y1, float y2, float y3, f16 h0, f16 h1, f16 h2, f16 h3) {
-    auto t = [](float y, f16 h) -> float {
-        const float r = __builtin_bit_cast(float, 0x88000000u - __builtin_bit_cast(unsigned, res_pow(h)));     // 2^(33-E)
-        return __builtin_fmaf(y - (float)h, r, 128.f);
+    auto t = [](float y, f16 h) -> float {        // (y - h) * 2^13: v_mul + v_fma_mix (the fp16 operand is read as such), clamped to e4m3's range
+        return __builtin_amdgcn_fmed3f(__builtin_fmaf(-(float)h, RES_SCALE, y * RES_SCALE), -448.f, 448.f);
     };
-    unsigned w = 0;
-    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y0, h0), 0, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y1, h1), 1, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y2, h2), 2, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(t(y3, h3), 3, w);
-    return w;
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(t(y0, h0), t(y1, h1), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(t(y2, h2), t(y3, h3), w, true);
+    return (unsigned)w;
 }
 #endif
 
@@ -167,6 +165,7 @@ void engine_opts_set_timeline(EngineOpts& o, bool on);
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
 hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStream_t s);
 bool gemm_ln_fusable(const GemmArgs& a);
+hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s);
 hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s);
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,

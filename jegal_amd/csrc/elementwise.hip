@@ -651,3 +651,30 @@ hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int
     hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, T, H, W, mask_y_dev, dst);
     return hipGetLastError();
 }
+
+// ---- masked crops over PCIe in fewer bytes ------------------------------------------------------------------
+// The reference blanks rows 0 .. y2+15 of every crop (inference_embs.py:264-270): ~40 % of the bytes of a batch are zeros the
+// engine then skips.  A producer ships only the rows BELOW each frame's mask, packed back to back; this kernel rebuilds the
+// dense (frames, 270, 480, 3) batch: frame f's rows >= row0[f] come from packed + offs[f], the rows above are zero.
+__global__ __launch_bounds__(256) void unpack_masked_kernel(const uint8_t* __restrict__ packed, const int* __restrict__ row0,
+                                                            const long long* __restrict__ offs, uint8_t* __restrict__ dst) {
+    constexpr int ROW_B = 480 * 3, ROW_V = ROW_B / 16, ROWS = 30;          // 90 16-byte pieces per row, 30 rows per block (9 blocks per frame)
+    const int f = blockIdx.x;
+    const int r_begin = blockIdx.y * ROWS;
+    const int r0 = row0[f];
+    const uint8_t* src = packed + offs[f];
+    uint8_t* out = dst + (size_t)f * (270 * ROW_B);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    for (int i = threadIdx.x; i < ROWS * ROW_V; i += 256) {
+        const int r = r_begin + i / ROW_V, c = i % ROW_V;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r >= r0) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (size_t)(r - r0) * ROW_B) + c);
+        reinterpret_cast<u32x4*>(out + (size_t)r * ROW_B)[c] = v;
+    }
+}
+
+hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s) {
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_masked_kernel, dim3((unsigned)n_frames, 9), dim3(256), 0, s, packed, row0, offs, dst);
+    return hipGetLastError();
+}

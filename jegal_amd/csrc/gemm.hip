@@ -488,18 +488,15 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
             }
 
         if constexpr (LNF) {
-            // expand the parked token-stream bits of this tile into fp32 accumulators (res_dec, common.h)
+            // expand the parked token-stream bits of this tile into fp32 accumulators (res_dec4, common.h)
             auto asu = [](float v) -> unsigned { return __builtin_bit_cast(unsigned, v); };
-            auto h2 = [](unsigned w, int hi) -> f16 { return __builtin_bit_cast(f16, (unsigned short)(hi ? w >> 16 : w & 0xffffu)); };
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 const f32x4 a0 = acc[0][j], a1 = acc[1][j], a2 = acc[2][j], a3 = acc[3][j];
                 const unsigned xw[4][2] = {{asu(a0.x), asu(a0.y)}, {asu(a1.x), asu(a1.y)}, {asu(a2.x), asu(a2.y)}, {asu(a0.z), asu(a0.w)}};
                 const unsigned dw[4] = {asu(a3.x), asu(a3.y), asu(a3.z), asu(a3.w)};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = f32x4{res_dec(h2(xw[i][0], 0), dw[i] & 0xffu), res_dec(h2(xw[i][0], 1), (dw[i] >> 8) & 0xffu),
-                                      res_dec(h2(xw[i][1], 0), (dw[i] >> 16) & 0xffu), res_dec(h2(xw[i][1], 1), dw[i] >> 24)};
+                for (int i = 0; i < 4; ++i) acc[i][j] = res_dec4(xw[i][0], xw[i][1], dw[i]);
             }
         }
         for (int kt = 0; kt < nk; ++kt) {

@@ -96,25 +96,79 @@ def gestsync_feats_to_npy(gestsync, clips, out_paths, rank=None, nshard=None):
     return done
 
 
+FRAME_ROW_BYTES = 480 * 3
+FRAME_BYTES = 270 * FRAME_ROW_BYTES
+
+
+class _MaskedPacker:
+    """Host side of the masked upload: the kept rows (>= row0) of every frame of a batch, back to back in a pinned buffer."""
+
+    def __init__(self, batch, T):
+        self.batch, self.T = batch, T
+        self.buf = torch.empty((batch * T * FRAME_BYTES,), dtype=torch.uint8).pin_memory()
+        self.row0 = torch.zeros((batch * T,), dtype=torch.int32).pin_memory()
+        self.offs = torch.zeros((batch * T,), dtype=torch.int64).pin_memory()
+        self.reset()
+
+    def reset(self):
+        self.n, self.used = 0, 0
+
+    def add(self, clip, row0):
+        """clip (T,270,480,3) uint8 whose rows < row0 are blank (not checked: they are simply not shipped); row0: int or (T,) ints."""
+        clip = np.asarray(clip)
+        if clip.shape != (self.T, 270, 480, 3) or clip.dtype != np.uint8:
+            raise ValueError(f"clip must be uint8 ({self.T},270,480,3), got {clip.dtype} {clip.shape}")
+        if self.n >= self.batch:
+            raise ValueError("batch is full")
+        r0 = np.broadcast_to(np.asarray(row0, np.int64), (self.T,))
+        if r0.min() < 0 or r0.max() > 270:
+            raise ValueError("row0 must be in 0..270")
+        f0 = self.n * self.T
+        kept = (270 - r0) * FRAME_ROW_BYTES
+        offs = self.used + np.concatenate(([0], np.cumsum(kept)[:-1]))
+        self.row0.numpy()[f0:f0 + self.T] = r0
+        self.offs.numpy()[f0:f0 + self.T] = offs
+        dst = self.buf.numpy()
+        if (r0 == r0[0]).all():                                   # one strided copy for a clip with one mask height
+            n = int(kept[0])
+            dst[self.used:self.used + self.T * n].reshape(self.T, n)[:] = clip[:, int(r0[0]):].reshape(self.T, n)
+        else:
+            for t in range(self.T):
+                dst[offs[t]:offs[t] + kept[t]] = clip[t, int(r0[t]):].reshape(-1)
+        self.used += int(kept.sum())
+        self.n += 1
+
+
 class GestureStreamer:
     """Streams host-resident clips through ``jg_extract_gesture`` with the uploads hidden behind the compute.
 
-    A 32-clip batch of uint8 crops is 1.87 GB; at PCIe Gen5 rates its upload takes longer than the 17 ms
+    A 32-clip batch of uint8 crops is 1.87 GB; at PCIe Gen5 rates its upload takes longer than the 12 ms
     the GPU needs for it, so a serving / dataset-extraction loop must keep the copy engine busy all the
     time: two pinned host buffers + two device buffers, batch k+1 is packed and copied (copy stream) while
     batch k runs (compute stream), batch k-1's embeddings go back on the copy stream.  torch is plumbing
     only (pinned memory, streams, events); the compute is one library call per batch.
+
+    ``masked=True`` ships fewer bytes: the reference blanks rows 0..y2+15 of every crop (inference_embs.py:264-270), the
+    producer knows y2, so only the rows below each frame's mask cross the host link (``run(clips, mask_rows)`` /
+    ``run_filled`` with a packer) and ``jg_unpack_masked`` rebuilds the dense batch on the device, on the upload stream.
+    Bit-identical to uploading the blanked crops whole.
 
     ``run(clips)``: ``clips`` iterates over (T,270,480,3) uint8 numpy arrays of one common T; yields
     ``(first_clip_index, embeddings (n,T,512) float32 numpy)`` per batch, in order.
     (The reference's loop does this synchronously per clip: inference_embs.py:476-522,629-637.)
     """
 
-    def __init__(self, engine, batch=32, frames=150):
-        self.eng, self.batch, self.T = engine, int(batch), int(frames)
+    def __init__(self, engine, batch=32, frames=150, masked=False):
+        self.eng, self.batch, self.T, self.masked = engine, int(batch), int(frames), bool(masked)
         dev = engine.device
         shape = (self.batch, self.T, 270, 480, 3)
-        self.h_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        if self.masked:
+            self.packer = [_MaskedPacker(self.batch, self.T) for _ in range(2)]
+            self.d_packed = [torch.empty((self.batch * self.T * FRAME_BYTES,), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.d_row0 = [torch.empty((self.batch * self.T,), dtype=torch.int32, device=dev) for _ in range(2)]
+            self.d_offs = [torch.empty((self.batch * self.T,), dtype=torch.int64, device=dev) for _ in range(2)]
+        else:
+            self.h_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.d_in = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(2)]
         self.d_out = [torch.empty((self.batch, self.T, 512), dtype=torch.float32, device=dev) for _ in range(2)]
         self.h_out = [torch.empty((self.batch, self.T, 512), dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -125,9 +179,17 @@ class GestureStreamer:
         self.computed = [torch.cuda.Event() for _ in range(2)]
         self.downloaded = [torch.cuda.Event() for _ in range(2)]
 
-    def _pack(self, it, slot):
+    def _pack(self, it, slot, rows_it=None):
         """Fill pinned buffer `slot` from the iterator; returns the number of clips packed."""
         n = 0
+        if self.masked:
+            pk = self.packer[slot]
+            pk.reset()
+            for clip in it:
+                pk.add(clip, 0 if rows_it is None else next(rows_it))
+                if pk.n == self.batch:
+                    break
+            return pk.n
         dst = self.h_in[slot].numpy()
         for clip in it:
             clip = np.asarray(clip)
@@ -139,23 +201,41 @@ class GestureStreamer:
                 break
         return n
 
-    def run(self, clips):
-        """clips: iterable of (T,270,480,3) uint8 arrays (copied into the pinned staging buffers here)."""
+    def run(self, clips, mask_rows=None):
+        """clips: iterable of (T,270,480,3) uint8 arrays (copied into the pinned staging buffers here).  masked streamer:
+        mask_rows iterates alongside and gives each clip's first unmasked row (int, or (T,) ints per frame); None = 0."""
         it = iter(clips)
-        return self.run_filled(lambda buf, k: self._pack(it, k & 1))
+        rows_it = None if mask_rows is None else iter(mask_rows)
+        if rows_it is not None and not self.masked:
+            raise ValueError("mask_rows needs GestureStreamer(..., masked=True)")
+        return self.run_filled(lambda buf, k: self._pack(it, k & 1, rows_it))
+
+    def _upload(self, slot, n):
+        """H2D of batch `slot` on the copy stream (+ the unpack kernel of the masked mode, also there)."""
+        with torch.cuda.stream(self.copy):
+            if self.masked:
+                pk = self.packer[slot]
+                F = n * self.T
+                self.d_packed[slot][:pk.used].copy_(pk.buf[:pk.used], non_blocking=True)
+                self.d_row0[slot][:F].copy_(pk.row0[:F], non_blocking=True)
+                self.d_offs[slot][:F].copy_(pk.offs[:F], non_blocking=True)
+                self.eng.unpack_masked(self.d_packed[slot], self.d_row0[slot][:F], self.d_offs[slot][:F], self.d_in[slot][:n])
+            else:
+                self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
+            self.uploaded[slot].record(self.copy)
 
     def run_filled(self, fill):
-        """fill(pinned_uint8_array (batch,T,270,480,3), batch_index) -> number of clips written (0 = end).
-        For producers (decoders) that can write their crops straight into the pinned buffer."""
+        """fill(buffer, batch_index) -> number of clips written (0 = end), for producers (decoders) that can write their crops
+        straight into pinned memory.  buffer: the pinned uint8 array (batch,T,270,480,3); masked streamer: the slot's
+        _MaskedPacker -- call reset() and add(clip, row0) per clip, or leave it as it is to re-send its content."""
         pending = []                      # (slot, first index, n) of batches whose embeddings are not yet returned
         first, k = 0, 0
-        n = fill(self.h_in[0].numpy(), 0)
+        buf = (lambda s_: self.packer[s_]) if self.masked else (lambda s_: self.h_in[s_].numpy())
+        n = fill(buf(0), 0)
         while n > 0 or pending:
             slot = k & 1
             if n > 0:
-                with torch.cuda.stream(self.copy):
-                    self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
-                    self.uploaded[slot].record(self.copy)
+                self._upload(slot, n)
                 with torch.cuda.stream(self.compute):
                     self.compute.wait_event(self.uploaded[slot])
                     self.eng.extract_gesture(self.d_in[slot][:n], self.d_out[slot][:n])
@@ -173,7 +253,7 @@ class GestureStreamer:
                 self.downloaded[s0].synchronize()
                 yield f0, self.h_out[s0][:n0].numpy().copy()
             k += 1
-            n = fill(self.h_in[k & 1].numpy(), k) if n > 0 else 0
+            n = fill(buf(k & 1), k) if n > 0 else 0
 
 
 # mediapipe face-mesh indices of the face oval (inference_embs.py:248-250)

@@ -112,6 +112,23 @@ def test_gesture_streamer_matches_resident_path():
     np.testing.assert_array_equal(np.concatenate([e for _, e in got2]), ref)
     with pytest.raises(ValueError):
         list(st.run([clips[0][:4]]))
+    # masked upload: only the rows below each frame's mask cross the link, jg_unpack_masked rebuilds the batch on the device
+    stm = GestureStreamer(eng, batch=3, frames=T, masked=True)
+    got3 = list(stm.run(iter(clips), mask_rows=[110] * n))
+    assert [f for f, _ in got3] == [0, 3, 6]
+    np.testing.assert_array_equal(np.concatenate([e for _, e in got3]), ref)
+    assert stm.packer[1].used == 3 * T * 160 * 480 * 3 and stm.packer[0].used == 1 * T * 160 * 480 * 3      # batches 1 (3 clips) and 2 (1 clip)
+    # per-frame mask heights (and a frame shipped whole, one not at all)
+    rng = np.random.default_rng(5)
+    rows = rng.integers(60, 150, (n, T))
+    rows[0, 0], rows[1, 2] = 0, 270
+    jit = rng.integers(1, 256, (n, T, 270, 480, 3), dtype=np.uint8)
+    for b in range(n):
+        for t in range(T):
+            jit[b, t, :rows[b, t]] = 0
+    refj = np.concatenate([eng.extract_gesture(torch.from_numpy(jit[i:i + 3]).cuda()).cpu().numpy() for i in range(0, n, 3)])
+    got4 = list(stm.run(iter(jit), mask_rows=list(rows)))
+    np.testing.assert_array_equal(np.concatenate([e for _, e in got4]), refj)
 
 
 @pytest.mark.parametrize("H,W", [(270, 480), (360, 640), (720, 1280), (301, 533), (135, 240)])
