@@ -1,6 +1,9 @@
 // libjegal_hip: handle, weight packing and the host-side orchestration of the HIP kernels behind
 // the C ABI of include/jegal_hip.h.  Host code only (no kernels here).
 #include "common.h"
+#define JG_BF16                  // the bf16 build's declarations (namespace bf): same launchers, f16 = __bf16
+#include "common.h"
+#undef JG_BF16
 #include "../../include/jegal_hip.h"
 
 #include <cmath>
@@ -11,6 +14,27 @@
 #include <vector>
 
 namespace {
+
+// ---- dispatch between the two kernel builds.  LAUNCH(h, launch_x, args...) calls launch_x of the fp16 build or bf::launch_x of
+// the bf16 build (precision mode JG_PREC_BF16): same argument lists, the 16-bit pointers and the structs that carry them are
+// layout-identical in both builds and simply re-typed.
+inline const bf::f16* to_bf(const f16* p) { return reinterpret_cast<const bf::f16*>(p); }
+inline bf::f16* to_bf(f16* p) { return reinterpret_cast<bf::f16*>(p); }
+inline const bf::GemmArgs& to_bf(const GemmArgs& a) { return reinterpret_cast<const bf::GemmArgs&>(a); }
+inline const bf::EngineOpts& to_bf(const EngineOpts& o) { return reinterpret_cast<const bf::EngineOpts&>(o); }
+static_assert(sizeof(bf::GemmArgs) == sizeof(GemmArgs) && sizeof(bf::EngineOpts) == sizeof(EngineOpts), "the two builds share their argument structs");
+template <class T> inline T to_bf(T v) { return v; }
+template <class F, class G, class... A>
+inline hipError_t dispatch_build(bool bf16, F f, G g, A... a) { return bf16 ? g(to_bf(a)...) : f(a...); }
+#define LAUNCH(h, fn, ...) dispatch_build((h)->bf16, fn, bf::fn, __VA_ARGS__)
+
+// fp32 -> bf16 bits, round to nearest even (host side of the weight packing)
+inline uint16_t bf16_bits(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 struct HostTensor {
     std::vector<float> v;
@@ -71,6 +95,7 @@ struct jg_handle {
     hipStream_t own_stream = nullptr;
     std::string err;
     int precision = JG_PREC_FP16_BC;
+    bool bf16 = false;             // precision == JG_PREC_BF16: every launcher comes from the bf16 build (namespace bf)
     bool calib = false;            // calibration pass in progress (bc layers use hi+lo and record input means)
     bool gs_calibrated = false, jg_calibrated = false;
     std::vector<Lin*> bc_layers;   // bias-corrected layers of both models (entries of a model are dropped on its re-finalize)
@@ -223,10 +248,17 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
                                        : (mode == JG_PREC_FP16_W2 || mode == JG_PREC_FP16_W2_ALL || (mode == JG_PREC_FP16_BC && kind == LK_CONTENT));
     std::vector<f16> hi((size_t)N * K), lo;
     if (split || bc) lo.resize((size_t)N * K);
-    for (size_t i = 0; i < hi.size(); ++i) {
-        const f16 a = (f16)w[i];
-        hi[i] = a;
-        if (split || bc) lo[i] = (f16)(w[i] - (float)a);
+    if (h->bf16) {                       // JG_PREC_BF16: single bf16 weights (the 16-bit container is re-typed by the bf16 build)
+        for (size_t i = 0; i < hi.size(); ++i) {
+            const uint16_t b = bf16_bits(w[i]);
+            std::memcpy(&hi[i], &b, 2);
+        }
+    } else {
+        for (size_t i = 0; i < hi.size(); ++i) {
+            const f16 a = (f16)w[i];
+            hi[i] = a;
+            if (split || bc) lo[i] = (f16)(w[i] - (float)a);
+        }
     }
     L->N = N; L->K = K;
     L->model = h->cur_model;
@@ -357,7 +389,7 @@ int finalize_gestsync(jg_handle* h) {
     RET(make_conv(h, "net_vid.conv5", "net_vid.bn5", 256, 256, 1, 3, 3, 256, 0, &h->c5, 1, 1, true));
     RET(make_conv(h, "net_vid.fc6", "net_vid.bn6", 512, 256, 1, 4, 4, 256, 0, &h->fc6));
     RET(upload(h, std::vector<float>(64, 1.0f / 255.0f), &h->c1_scale255));
-    {   // slot-major copy of the packed conv1 panel for conv1_direct_kernel: Wd[s][o][e] = W[o][s*16+e]
+    if (!h->bf16) {   // slot-major copy of the packed conv1 panel for conv1_direct_kernel: Wd[s][o][e] = W[o][s*16+e]
         std::vector<f16> hostw((size_t)64 * 784), wd((size_t)49 * 64 * 16);
         HIPCHK(h, hipMemcpy(hostw.data(), h->c1.wh, hostw.size() * sizeof(f16), hipMemcpyDeviceToHost));
         for (int s = 0; s < 49; ++s)
@@ -402,9 +434,12 @@ int finalize_jegal(jg_handle* h) {
     for (auto& L : h->rgb_layers) L = EncLayer();
     for (auto& L : h->text_layers) L = EncLayer();
     h->wallocs = &h->wallocs_jg;
-    RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0));
+    // The input projection keeps hi+lo weights in the bias-corrected mode too: the zero-padded rows of a ragged batch
+    // (dataset.py:336-340) reach it as x = 0 exactly, where a bias correction (w - fp16(w)).E[x] would be pure error -- the
+    // reference computes those rows as well (callers strip them).  Two small GEMMs of the 50 in the branch.
+    RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0, LK_CONTENT));
     RET(make_ln(h, "proj_ip_rgb.1.weight", "proj_ip_rgb.1.bias", 512, &h->ip_ln));
-    RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3));
+    RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3, LK_CONTENT));
     const HostTensor* pe;
     RET(need(h, "position_rgb.pe", 500 * 512, &pe));
     RET(upload(h, pe->v, &h->rgb_pe));
@@ -474,7 +509,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
         RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, part, Lm.mu, h->stream); }));
         Lm.mu_rows += M;
     }
-    return timed(h, stage, [&] { return launch_gemm(a, conv, h->opts, h->stream); });
+    return timed(h, stage, [&] { return LAUNCH(h, launch_gemm, a, conv, h->opts, h->stream); });
 }
 
 ConvGeom geom(int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW, bool reorder = false) {
@@ -535,7 +570,9 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     RET(wsalloc(h, (size_t)NF * 4 * 4 * 256, &p5));
     Epi e;
     e.relu = 1;
-    const bool direct = src_u8 && sc == 1 && sw == 3 && sh == (long)FW * 3 && st == (long)FH * FW * 3 && sb == (long)T * st && h->conv1_direct;
+    // (the direct kernel feeds u8 pixels to the MFMA as fp16 subnormals: fp16 build only; JG_PREC_BF16 stacks the frames and runs
+    // conv1 as an implicit GEMM)
+    const bool direct = src_u8 && sc == 1 && sw == 3 && sh == (long)FW * 3 && st == (long)FH * FW * 3 && sb == (long)T * st && h->conv1_direct && !h->bf16;
     if (direct) {
         // u8 HWC video: conv1 + max-pool straight from the frames; neither the temporal stack nor the
         // pre-pool tensor exists in HBM
@@ -573,18 +610,18 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
     } else {
         RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
         RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
-        RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
+        RET(timed(h, JG_ST_STACK, [&] { return LAUNCH(h, launch_stack_frames, src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
         e.scale = src_u8 ? h->c1_scale255 : nullptr;
         e.out16 = o1;
         RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
-        RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
+        RET(timed(h, JG_ST_POOL, [&] { return LAUNCH(h, launch_maxpool3x3s2, o1, p1, (int)NF, 88, 158, 64, h->stream, nullptr, 0, nullptr); }));
     }
     e.scale = nullptr;
     e.out16 = o2; RET(gemm(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, e, &g2));
     e.out16 = o3; RET(gemm(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, e, &g3));
     e.out16 = o4; RET(gemm(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, e, &g4));
     e.out16 = o5; RET(gemm(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, e, &g5));
-    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o5, p5, (int)NF, 10, 10, 256, h->stream, s2pos, 3, h->gs_c5C); }));
+    RET(timed(h, JG_ST_POOL, [&] { return LAUNCH(h, launch_maxpool3x3s2, o5, p5, (int)NF, 10, 10, 256, h->stream, s2pos, 3, h->gs_c5C); }));
     e.out16 = conv16; e.out32 = conv_out;
     RET(gemm(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, e));
     return JG_OK;
@@ -596,7 +633,7 @@ int gs_conv_stack(jg_handle* h, const void* src, int src_u8, long sb, long st, l
 // 4 copies per layer so that every launch has the 256 rows the LDS-DMA kernel needs.
 int gs_build_const_chain(jg_handle* h) {
     h->gs_c2C = h->gs_c3C = h->gs_c4C = h->gs_c5C = nullptr;
-    if (!h->opts.gemm_glds) return JG_OK;
+    if (!h->opts.gemm_glds || h->bf16) return JG_OK;      // the chain starts from conv1_direct's constant (fp16 build only)
     constexpr int NC = 4;
     f16 *zc, *poolC, *c2C, *c3C, *c4C, *c5C;
     h->wallocs = &h->wallocs_gs;
@@ -628,7 +665,7 @@ int gs_build_const_chain(jg_handle* h) {
 // All twelve projections must qualify (single-fp16 weights, not the calibration pass): the fused kernel keeps the
 // fp32 residual stream in its own tiled order (gemm.hip), so fused and unfused layers cannot be mixed.
 bool gs_fused_plan(const jg_handle* h, int M) {
-    if (!h->fuse_ln || !h->opts.gemm_glds || h->calib || M < 1024) return false;      // the tiled token stream is read by LDS-DMA only
+    if (!h->fuse_ln || !h->opts.gemm_glds || h->calib || M < 1024 || h->bf16) return false;     // (the token stream's codec is fp16 + fp8)      // the tiled token stream is read by LDS-DMA only
     for (int l = 0; l < 6; ++l)
         if (h->gs_layers[l].out.wl || h->gs_layers[l].ff2.wl) return false;
     return true;
@@ -674,7 +711,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             Epi e;
             e.out16 = qkv; e.a_tiled = tiled;
             RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
-            RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
+            RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
         }
         // out_proj / linear2 with the residual add and the post-norm LayerNorm fused into the epilogue (row-wide
         // 128x512 tiles, tiled fp16 + 8-bit token stream) when gs_fused_plan() says so; otherwise GEMM + LayerNorm kernel.
@@ -686,7 +723,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             }
             r.res = x32; r.ldr = 512; r.out32 = x32;
             RET(gemm(h, JG_ST_GEMM, A, lda, M, W, r));
-            return timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, ln.w, ln.b, M, 512, LN_STD, 0, x32, x16, h->stream); });
+            return timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, ln.w, ln.b, M, 512, LN_STD, 0, x32, x16, h->stream); });
         };
         RET(proj_ln(att, 512, L.out, L.n1));
         Epi f;
@@ -725,14 +762,14 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv, conv16));
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
         const Qkv0 q0 = {conv16, nb, P, T, 12 - PAD};
         RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
         Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_group_mean(hid, nseq, S, 512, mean16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_group_mean, hid, nseq, S, 512, mean16, h->stream); }));
         Epi o; o.out32 = out_feats + (size_t)b0 * T * 1024;
         RET(gemm(h, JG_ST_GEMM, mean16, 512, nseq, h->ff2, o));
     }
@@ -758,7 +795,7 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
         const bool tiled = gs_fused_plan(h, M);
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled, x32, x16, h->stream); }));
         RET(gs_transformer(h, x32, x16, nb, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)M * 1024, &full));
@@ -782,18 +819,18 @@ int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& f
     RET(wsalloc(h, (size_t)M * Dff, &hid));
     for (int l = 0; l < nl; ++l) {
         const EncLayer& L = layers[l];
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
         Epi e; e.out16 = qkv;
         RET(gemm(h, JG_ST_GEMM, n16, D, M, L.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mask, B, S, H, dk, att, h->opts, h->stream); }));
+        RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mask, B, S, H, dk, att, h->opts, h->stream); }));
         Epi r; r.res = x32; r.ldr = D; r.out32 = x32;
         RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
         Epi f; f.relu = 1; f.out16 = hid;
         RET(gemm(h, JG_ST_GEMM, n16, D, M, L.ff1, f));
         RET(gemm(h, JG_ST_GEMM, hid, Dff, M, L.ff2, r));
     }
-    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
     return JG_OK;
 }
 
@@ -808,10 +845,10 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     RET(wsalloc(h, (size_t)M * 512, &t16));
     RET(wsalloc(h, (size_t)M * 512, &x32));
     RET(wsalloc(h, (size_t)M * 512, &n16));
-    RET(timed(h, JG_ST_MISC, [&] { return launch_cast_f32_f16(feats, f16in, (long)M * 1024, h->stream); }));
+    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, feats, f16in, (long)M * 1024, h->stream); }));
     Epi e; e.out32 = t32;
     RET(gemm(h, JG_ST_GEMM, f16in, 1024, M, h->ip0, e));
-    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, nullptr, t16, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, nullptr, t16, h->stream); }));
     Epi p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T; p.out32 = x32;
     RET(gemm(h, JG_ST_GEMM, t16, 512, M, h->ip3, p));
     RET(annotated_encoder(h, h->rgb_layers, 6, h->rgb_norm, x32, n16, mask, B, T, 512, 2048));
@@ -938,7 +975,7 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) 
     RET(wsalloc(h, (size_t)B * g9.OH * g9.OW * 256, &c9));
     RET(wsalloc(h, (size_t)B * g12.OH * g12.OW * 256, &c12));
     RET(wsalloc(h, (size_t)B * g15.OH * 256, &c15));
-    RET(timed(h, JG_ST_MISC, [&] { return launch_im2col_mel(mel, B, Tm, F, col, h->stream); }));
+    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_im2col_mel, mel, B, Tm, F, col, h->stream); }));
     Epi e; e.relu = 1;
     e.out16 = c0; RET(gemm(h, JG_ST_CONV, col, 32, (int)M0, h->a0, e));
     e.out16 = c3; RET(gemm(h, JG_ST_CONV, c0, 0, B * g3.OH * g3.OW, h->a3, e, &g3));
@@ -1038,21 +1075,21 @@ int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int
         RET(timed(h, JG_ST_MISC, [&] { return launch_mask_i32_f32(amask, mk, M, h->stream); }));
     }
     RET(timed(h, JG_ST_MISC, [&] { return launch_xlmr_embed(ids, B, L, D, 1, h->xl_vocab, h->xl_maxpos, h->xl_word, h->xl_pos, h->xl_type, t32, h->stream); }));
-    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->xl_emb_ln.w, h->xl_emb_ln.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, h->xl_emb_ln.w, h->xl_emb_ln.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
     for (int l = 0; l < h->xl_layers_n; ++l) {
         const EncLayer& Ly = h->xl_layers[l];
         const bool last = l + 1 == h->xl_layers_n;
         Epi e; e.out16 = qkv;
         RET(gemm(h, JG_ST_GEMM, x16, D, M, Ly.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention(qkv, mk, B, L, H, 64, att, h->opts, h->stream); }));
+        RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mk, B, L, H, 64, att, h->opts, h->stream); }));
         Epi r; r.res = x32; r.ldr = D; r.out32 = t32;
         RET(gemm(h, JG_ST_GEMM, att, D, M, Ly.out, r));
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n1.w, Ly.n1.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, Ly.n1.w, Ly.n1.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
         Epi f; f.out32 = t32;
         RET(gemm(h, JG_ST_GEMM, x16, D, M, Ly.ff1, f));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_gelu(t32, hid, (long)M * DFF, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_gelu, t32, hid, (long)M * DFF, h->stream); }));
         RET(gemm(h, JG_ST_GEMM, hid, DFF, M, Ly.ff2, r));
-        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n2.w, Ly.n2.b, M, D, LN_STD, 0, last ? out : x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, Ly.n2.w, Ly.n2.b, M, D, LN_STD, 0, last ? out : x32, x16, h->stream); }));
     }
     return JG_OK;
 }
@@ -1064,7 +1101,7 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     RET(wsalloc(h, (size_t)rows * 512, &x16));
     RET(wsalloc(h, (size_t)rows * 512, &a16));
     RET(wsalloc(h, (size_t)rows * 512, &b16));
-    RET(timed(h, JG_ST_MISC, [&] { return launch_cast_f32_f16(fused, x16, (long)rows * 512, h->stream); }));
+    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, fused, x16, (long)rows * 512, h->stream); }));
     Epi r; r.relu = 1; r.out16 = a16;
     RET(gemm(h, JG_ST_GEMM, x16, 512, rows, h->fu0, r));
     Epi p; p.out16 = b16;
@@ -1170,9 +1207,10 @@ int jg_set_stream(jg_handle* h, void* s) {
 
 int jg_set_precision(jg_handle* h, int mode) {
     if (!h) return JG_ERR_ARG;
-    if (mode < JG_PREC_FP16 || mode > JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
-    if ((h->gs_ready || h->jg_ready) && mode != h->precision) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
+    if (mode < JG_PREC_FP16 || mode > JG_PREC_BF16) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
+    if ((h->gs_ready || h->jg_ready || h->xl_ready) && mode != h->precision) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
     h->precision = mode;
+    h->bf16 = mode == JG_PREC_BF16;
     return JG_OK;
 }
 
@@ -1306,7 +1344,7 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     h->ws.reset();
     const int P = T + 2 * pad - 4;
     const long NF = (long)B * P;
-    if (h->conv1_direct) {
+    if (h->conv1_direct && !h->bf16) {
         f16* edge;
         unsigned* zscr;
         RET(wsalloc(h, conv1_edge_elems(NF), &edge));
@@ -1317,11 +1355,11 @@ int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int p
     RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
     RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
     const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
-    RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames(frames_u8, 1, sb, st, sh, sw, 1, B, T, pad, FH, FW, S, h->stream); }));
+    RET(timed(h, JG_ST_STACK, [&] { return LAUNCH(h, launch_stack_frames, frames_u8, 1, sb, st, sh, sw, 1, B, T, pad, FH, FW, S, h->stream); }));
     const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);
     Epi e; e.relu = 1; e.scale = h->c1_scale255; e.out16 = o1;
     RET(gemm(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, e, &g1));
-    return timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2(o1, static_cast<f16*>(out_f16), (int)NF, 88, 158, 64, h->stream); });
+    return timed(h, JG_ST_POOL, [&] { return LAUNCH(h, launch_maxpool3x3s2, o1, static_cast<f16*>(out_f16), (int)NF, 88, 158, 64, h->stream, nullptr, 0, nullptr); });
 }
 
 // Tuning aid: time `iters` launches of the production GEMM on garbage operands of a given shape.
@@ -1364,9 +1402,9 @@ int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int 
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, launch_gemm(a, false, h->opts, h->stream));
+    HIPCHK(h, LAUNCH(h, launch_gemm, a, false, h->opts, h->stream));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(a, false, h->opts, h->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, LAUNCH(h, launch_gemm, a, false, h->opts, h->stream));
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
     float t = 0.f;
@@ -1435,7 +1473,7 @@ int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attent
 int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {
     ENTER(h);
     if (!seq || !seg || !dst) JG_FAIL(h, JG_ERR_ARG, "null buffer");
-    return timed(h, JG_ST_MISC, [&] { return launch_segment_mean(seq, D, seg, n, nullptr, dst, dst_ld, dst_col, h->stream); });
+    return timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_segment_mean, seq, D, seg, n, nullptr, dst, dst_ld, dst_col, h->stream); });
 }
 
 int jg_fuse_content(jg_handle* h, const float* fused, int rows, float* out) {

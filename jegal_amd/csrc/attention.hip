@@ -13,6 +13,8 @@
 //                            over blocks of 8 keys, fp32 state.  For S <= 32 one wave carries floor(64/S) (sequence, head) pairs.
 #include "common.h"
 
+JG_NS_BEGIN
+
 template <int DK>
 __global__ __launch_bounds__(256) void attn_kernel(const f16* __restrict__ qkv, const float* __restrict__ keymask,
                                                    int B, int S, int H, int G, f16* __restrict__ out) {
@@ -111,7 +113,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const f16* __restrict__ qkv, 
                         const f16x8 k8 = *reinterpret_cast<const f16x8*>(kr + v * 8);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
+#ifdef JG_BF16
+                            acc = __builtin_fmaf((float)q[v * 4 + e].x, (float)k8[2 * e], __builtin_fmaf((float)q[v * 4 + e].y, (float)k8[2 * e + 1], acc));
+#else
                             acc = __builtin_amdgcn_fdot2(q[v * 4 + e], f16x2{k8[2 * e], k8[2 * e + 1]}, acc, false);
+#endif
                     }
                     acc *= scale;
                     if (sM[kbase + j] == 0.f) acc = -1e9f;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256, 5) void attn_mfma_s32_kernel(const f16* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kA[s], qB[s], sc, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) sc = JG_MFMA_32x32x16(kA[s], qB[s], sc);
 
     // ---- softmax over keys: register i <-> key (i&3) + 8(i>>2) + 4*hh
     const float scale = 0.125f;                       // 1/sqrt(64)
@@ -319,8 +325,8 @@ __global__ __launch_bounds__(256, 5) void attn_mfma_s32_kernel(const f16* __rest
             const char* vp = sVt + (r31 + 32 * blk) * VT_PITCH + (16 * s + 4 * hh) * 2;
             const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
             const f16x8 vA = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pH[s], o[blk], 0, 0, 0);
-            o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pL[s], o[blk], 0, 0, 0);
+            o[blk] = JG_MFMA_32x32x16(vA, pH[s], o[blk]);
+            o[blk] = JG_MFMA_32x32x16(vA, pL[s], o[blk]);
         }
     }
     // ---- O^T (register i <-> d = (i&3) + 8(i>>2) + 4*hh + 32*blk, lane <-> query) -> [query][d] fp16 in LDS -> rows
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64 * NB) void attn_mfma_kernel(const f16* __restric
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const f16x8 kA = *reinterpret_cast<const f16x8*>(sK + (32 * kb + r31) * K_PITCH + (16 * s + 8 * hh) * 2);
-            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kA, qB[s], sc[kb], 0, 0, 0);
+            sc[kb] = JG_MFMA_32x32x16(kA, qB[s], sc[kb]);
         }
     }
     // ---- softmax over the keys: register i of tile kb <-> key 32kb + (i&3) + 8(i>>2) + 4*hh
@@ -452,8 +458,8 @@ __global__ __launch_bounds__(64 * NB) void attn_mfma_kernel(const f16* __restric
                 const char* vp = sVt + (r31 + 32 * blk) * VT_PITCH + (32 * kb + 16 * s + 4 * hh) * 2;
                 const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
                 const f16x8 vA = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pH, o[blk], 0, 0, 0);
-                o[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vA, pL, o[blk], 0, 0, 0);
+                o[blk] = JG_MFMA_32x32x16(vA, pH, o[blk]);
+                o[blk] = JG_MFMA_32x32x16(vA, pL, o[blk]);
             }
         }
     // ---- back to [query][d] rows through this wave's LDS slice (aliases the K image: every wave is done with K)
@@ -527,3 +533,5 @@ hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, 
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+JG_NS_END

@@ -1,9 +1,33 @@
 // Shared device/host declarations for libjegal_hip (gfx950 only).
-#pragma once
+//
+// Two builds of the kernels live in the library: the default one with fp16 operands and, for precision mode JG_PREC_BF16, a
+// second one of gemm.hip / attention.hip / elementwise.hip compiled with -DJG_BF16: there `f16` -- the 16-bit operand /
+// activation type of every kernel -- is __bf16, the MFMA macros below name the bf16 instructions, and everything (this header
+// included) sits in namespace bf.  api.hip includes this header twice and dispatches per handle (LAUNCH in api.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if (defined(JG_BF16) && !defined(JG_COMMON_BF16_INCLUDED)) || (!defined(JG_BF16) && !defined(JG_COMMON_FP16_INCLUDED))
+#undef JG_NS_BEGIN
+#undef JG_NS_END
+#undef JG_MFMA_16x16x32
+#undef JG_MFMA_32x32x16
+#ifdef JG_BF16
+#define JG_COMMON_BF16_INCLUDED
+#define JG_NS_BEGIN namespace bf {
+#define JG_NS_END }
+namespace bf {
+typedef __bf16 f16;
+#define JG_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define JG_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#else
+#define JG_COMMON_FP16_INCLUDED
+#define JG_NS_BEGIN
+#define JG_NS_END
 typedef _Float16 f16;
+#define JG_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define JG_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
@@ -223,3 +247,8 @@ hipError_t launch_spot(const float* g, const float* c, const int32_t* goff, cons
                        int n, int D, float temp, int32_t* pred, float* score, hipStream_t s);
 hipError_t launch_asd(const float* q, const float* cand, const int32_t* coff, int n, int D, float temp,
                       int32_t* pred2, hipStream_t s);
+
+#ifdef JG_BF16
+}  // namespace bf
+#endif
+#endif  // this build's declarations

@@ -3,6 +3,8 @@
 // vector accesses wherever the layout allows (guide G13).
 #include "common.h"
 
+JG_NS_BEGIN
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -678,3 +680,5 @@ hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const lo
     hipLaunchKernelGGL(unpack_masked_kernel, dim3((unsigned)n_frames, 9), dim3(256), 0, s, packed, row0, offs, dst);
     return hipGetLastError();
 }
+
+JG_NS_END

@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 
+JG_NS_BEGIN
+
 template <int WM, int WN, bool CONV, bool W2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN, XR = BM / 32, WR = BN / 32;
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                    if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xf[j], acc[i][j]);
+                    if (W2) acc[i][j] = JG_MFMA_16x16x32(wl[i], xf[j], acc[i][j]);
                 }
         }
         __syncthreads();
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int j = 0; j < MI; ++j) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
-                        if (W2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xq[j % 3], acc[i][j], 0, 0, 0);
+                        acc[i][j] = JG_MFMA_16x16x32(wf[i], xq[j % 3], acc[i][j]);
+                        if (W2) acc[i][j] = JG_MFMA_16x16x32(wl[i], xq[j % 3], acc[i][j]);
                     }
                     if (j + 2 < MI) xq[(j + 2) % 3] = ldx(j + 2);
                     if (SPREAD && pre) {
@@ -990,3 +992,5 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStr
         return w2 ? launch_glds<true, false>(a, o, s) : launch_glds<false, false>(a, o, s);
     return w2 ? launch_variant<2, 2, false, true>(a, s) : launch_variant<2, 2, false, false>(a, s);
 }
+
+JG_NS_END

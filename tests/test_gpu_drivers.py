@@ -117,7 +117,11 @@ def test_gesture_streamer_matches_resident_path():
     got3 = list(stm.run(iter(clips), mask_rows=[110] * n))
     assert [f for f, _ in got3] == [0, 3, 6]
     np.testing.assert_array_equal(np.concatenate([e for _, e in got3]), ref)
-    assert stm.packer[1].used == 3 * T * 160 * 480 * 3 and stm.packer[0].used == 1 * T * 160 * 480 * 3      # batches 1 (3 clips) and 2 (1 clip)
+    from jegal_amd.extract import _MaskedPacker
+    pk = _MaskedPacker(3, T)
+    for b in range(3):
+        pk.add(clips[b], 110)
+    assert pk.n == 3 and pk.used == 3 * T * 160 * 480 * 3            # 160 of 270 rows cross the link
     # per-frame mask heights (and a frame shipped whole, one not at all)
     rng = np.random.default_rng(5)
     rows = rng.integers(60, 150, (n, T))

@@ -66,10 +66,10 @@ def test_jegal_gesture_long_clips(models, oracle_sd, T):
     r0, r1 = rel(out[0], ref[0]), rel(out[1, :valid], ref[1, :valid])
     print(f"T={T}: rel {r0:.3e} / {r1:.3e} (padded clip, valid rows)")
     assert r0 < TOL and r1 < TOL
-    # The reference also computes the PADDED query rows of clip 1 (zero feature rows; the caller strips them).  Their inputs are
-    # nothing like a clip's (x = 0, where the bias correction (w - fp16(w)).E[x] of the default precision mode is pure error):
-    # they are held to 2e-3, the rows that exist to 1e-3.
-    assert rel(out[1], ref[1]) < 2e-3
+    # The reference also computes the PADDED query rows of clip 1 (zero feature rows; the caller strips them): held to the
+    # same 1e-3.  (Round 2 allowed 2e-3: the bias correction (w - fp16(w)).E[x] of the default mode is pure error on x = 0;
+    # the input projection proj_ip_rgb now keeps hi+lo weights in that mode, api.hip finalize_jegal.)
+    assert rel(out[1], ref[1]) < TOL and rel(out[1, valid:], ref[1, valid:]) < TOL
 
 
 @pytest.mark.parametrize("L", [33, 70, 200])

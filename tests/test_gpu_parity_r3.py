@@ -1,0 +1,124 @@
+"""GPU parity tests added in round 3 (run with -m gpu): the bf16 reported mode next to the fp16 modes, the padded query rows of
+ragged JEGAL batches per precision mode, the masked upload's unpack kernel.  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import jegal_oracle as O
+from jegal_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def oracle_sd():
+    return O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+
+
+def _engine(mode):
+    from jegal_amd._lib import Engine
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    e = Engine(0, precision=mode)
+    GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    jg = JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+    return e, jg
+
+
+def test_precision_modes_report(oracle_sd):
+    """north_star and BASELINE configs[2] name bf16.  JG_PREC_BF16 runs every GEMM / conv / attention MFMA of
+    the path as a bf16 MFMA on bf16 weights and activations; its measured error on a full-length clip is REPORTED next to the
+    fp16 modes.  The fp16 modes with a weight remedy hold the 1e-3 contract, bf16 does not (8 significant bits) -- that, with
+    a GPU number, is why fp16 is the default.  The bf16 figure is asserted to be finite, of the expected order and worse than
+    every fp16 mode, not to pass."""
+    from jegal_amd._lib import PREC_FP16, PREC_FP16_W2, PREC_FP16_BC, PREC_BF16
+    gsd, jsd = oracle_sd
+    T = 150
+    frames = synth.synth_frames(1234, 1, T)
+    with torch.no_grad():
+        f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[0].astype(np.float32) / np.float32(255.0)))
+        ref = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
+    err, mx = {}, {}
+    for name, mode in (("fp16", PREC_FP16), ("fp16_w2", PREC_FP16_W2), ("fp16_bc", PREC_FP16_BC), ("bf16", PREC_BF16)):
+        e, _ = _engine(mode)
+        out = e.extract_gesture(torch.from_numpy(frames).cuda())[0]
+        assert torch.isfinite(out).all()
+        err[name] = rel(out, ref)
+        mx[name] = float((out.cpu() - ref).abs().max())
+        e.close()
+    print("precision modes, rel-L2 of the unit-norm gesture embedding vs the fp32 oracle (T = 150):",
+          {k: f"{v:.2e}" for k, v in err.items()}, "max-abs:", {k: f"{v:.2e}" for k, v in mx.items()})
+    assert err["fp16_w2"] < TOL and err["fp16_bc"] < TOL
+    assert max(err["fp16"], err["fp16_w2"], err["fp16_bc"]) < err["bf16"] < 5e-2
+
+
+def test_bf16_content_path_is_reported(oracle_sd):
+    """The tri-modal content path (audio CNN, text encoder, word pooling, fusion) in JG_PREC_BF16: finite, of bf16 order."""
+    from jegal_amd._lib import PREC_BF16
+    _, jsd = oracle_sd
+    B, T, W = 2, 40, 6
+    mel = synth.synth_mel(31, B, 4 * T)
+    states, tmask, ids, offs = synth.synth_text(32, B, W)
+    wbs = synth.synth_boundaries(B, W, stride=6, length=4)
+    tbatch = [[w[0] for w in wb] for wb in wbs]
+    pack = (torch.from_numpy(states), torch.from_numpy(tmask), tbatch, ids, offs)
+    with torch.no_grad():
+        ref = O.jegal_forward_inference(jsd, text=pack, audio=torch.from_numpy(mel), audio_mask=None, word_boundaries=wbs)
+    e, jg = _engine(PREC_BF16)
+    out = jg.forward_inference(text=pack, audio=torch.from_numpy(mel), word_boundaries=wbs)
+    r = rel(e.l2norm(out), O.l2_normalize(ref))
+    print(f"bf16 content embedding rel-L2 vs oracle: {r:.2e}")
+    e.close()
+    assert torch.isfinite(out).all() and r < 5e-2
+
+
+def test_padded_query_rows_per_precision_mode(oracle_sd):
+    """Ragged JEGAL batches (dataset.py:336-340): the reference also computes the zero-padded QUERY rows (callers strip them).
+    Their first Linear sees x = 0 exactly, where a bias correction (w - fp16(w)).E[x] would be pure error (measured in round 2:
+    1.8e-3 on those rows), so proj_ip_rgb keeps hi+lo weights in the default mode.  Valid AND padded rows hold 1e-3 in both modes."""
+    from jegal_amd._lib import PREC_FP16_W2, PREC_FP16_BC
+    _, jsd = oracle_sd
+    T, valid = 150, 113
+    rng = np.random.default_rng(850)
+    vf = rng.standard_normal((2, T, 1024)).astype(np.float32)
+    vf[1, valid:] = 0
+    vm = np.ones((2, T), np.float32)
+    vm[1, valid:] = 0
+    with torch.no_grad():
+        ref = O.jegal_forward_inference(jsd, visual_feats=torch.from_numpy(vf), visual_mask=torch.from_numpy(vm))
+    res = {}
+    for name, mode in (("fp16_w2", PREC_FP16_W2), ("fp16_bc", PREC_FP16_BC)):
+        e, jg = _engine(mode)
+        out = jg.forward_inference(visual_feats=torch.from_numpy(vf).cuda(), visual_mask=torch.from_numpy(vm).cuda())
+        res[name] = (rel(out[1, :valid], ref[1, :valid]), rel(out[1, valid:], ref[1, valid:]))
+        e.close()
+    print("padded clip (valid rows, padded rows) rel-L2:", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in res.items()})
+    for a, _ in res.values():
+        assert a < TOL
+    assert res["fp16_w2"][1] < TOL and res["fp16_bc"][1] < TOL
+
+
+def test_unpack_masked_rebuilds_the_dense_batch():
+    from jegal_amd._lib import Engine
+    eng = Engine.get("cuda:0")
+    rng = np.random.default_rng(3)
+    F = 7
+    rows = np.array([0, 110, 270, 1, 269, 135, 64], np.int32)
+    dense = rng.integers(1, 256, (F, 270, 480, 3), dtype=np.uint8)
+    packed, offs, off = [], [], 0
+    for f in range(F):
+        dense[f, :rows[f]] = 0
+        offs.append(off)
+        packed.append(dense[f, rows[f]:].reshape(-1))
+        off += packed[-1].size
+    packed = np.concatenate(packed + [np.zeros(16, np.uint8)])
+    dst = torch.full((F, 270, 480, 3), 7, dtype=torch.uint8, device="cuda")
+    eng.unpack_masked(torch.from_numpy(packed).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(np.array(offs, np.int64)).cuda(), dst)
+    assert np.array_equal(dst.cpu().numpy(), dense)
