@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -190,6 +191,13 @@ int timed(jg_handle* h, int stage, F&& f) {
     }
     hipError_t e = f();
     if (e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "kernel launch failed (stage %s): %s", jg_stage_name(stage), hipGetErrorString(e));
+    static const bool dbg_sync = getenv("JG_DEBUG_SYNC") != nullptr;      // fault hunting: name the launch a memory fault belongs to
+    if (dbg_sync) {
+        static long n = 0;
+        std::fprintf(stderr, "[jg] launch %ld (stage %s) ...", ++n, jg_stage_name(stage));
+        e = hipStreamSynchronize(h->stream);
+        std::fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+    }
     if (prof) {
         HIPCHK(h, hipEventRecord(r.e1, h->stream));
         h->recs.push_back(r);
@@ -239,11 +247,11 @@ int need(jg_handle* h, const std::string& name, int64_t numel, const HostTensor*
 
 // [N][K] fp32 -> device fp16 hi (+lo)
 // layer kinds: which precision treatment a matrix gets under the handle's mode
-enum { LK_CONV = 0, LK_GESTURE = 1, LK_CONTENT = 2 };
+enum { LK_CONV = 0, LK_GESTURE = 1, LK_CONTENT = 2, LK_XLMR = 3 };      // LK_XLMR: bias-corrected like the gesture path (calibrated on token ids)
 
 int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L) {
     const int mode = h->precision;
-    const bool bc = mode == JG_PREC_FP16_BC && kind == LK_GESTURE;
+    const bool bc = mode == JG_PREC_FP16_BC && (kind == LK_GESTURE || kind == LK_XLMR);
     const bool split = kind == LK_CONV ? mode == JG_PREC_FP16_W2_ALL
                                        : (mode == JG_PREC_FP16_W2 || mode == JG_PREC_FP16_W2_ALL || (mode == JG_PREC_FP16_BC && kind == LK_CONTENT));
     std::vector<f16> hi((size_t)N * K), lo;
@@ -541,6 +549,12 @@ constexpr int FH = 270, FW = 480;
 // fill_all = false: the caller's conv2 honours the row skip the scan leaves in zscr, so the pooled rows it never reads stay unwritten
 int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pad, f16* pooled, f16* edge, unsigned* zscr, bool fill_all) {
     const bool scan = h->opts.conv1_zero_skip;
+    if (getenv("JG_DEBUG_SYNC")) {
+        const long NFd = (long)nclip * (T + 2 * pad - 4);
+        std::fprintf(stderr, "[jg] conv1: src %p..%p pooled %p..%p edge %p..%p zscr %p..%p fill_all %d\n", (const void*)src,
+                     (const void*)(src + (size_t)nclip * T * FH * FW * 3), (void*)pooled, (void*)(pooled + (size_t)NFd * 43 * 78 * 64), (void*)edge,
+                     (void*)(edge + conv1_edge_elems(NFd)), (void*)zscr, (void*)(zscr + conv1_zmask_elems(nclip, T)), (int)fill_all);
+    }
     if (scan) RET(timed(h, JG_ST_CONV1_AUX, [&] { return launch_conv1_scan(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, zscr, h->stream); }));
     RET(timed(h, JG_ST_CONV1, [&] { return launch_conv1_direct(src, nclip, T, pad, h->c1_direct, 1.0f / 255.0f, pooled, edge,
                                                                scan ? zscr : nullptr, fill_all, h->opts, h->stream); }));
@@ -896,6 +910,44 @@ int apply_bias_corrections(jg_handle* h, int models) {
     return JG_OK;
 }
 
+int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out);
+
+// Bias corrections of the XLM-RoBERTa layers: one pass over built-in token ids (uniform over the vocabulary, no padding) with
+// hi+lo weights records every Linear's input means.  (E[x] behind a LayerNorm is mostly its beta and the mean of the position /
+// type embeddings: it depends little on WHICH tokens are drawn.)
+int calibrate_xlmr(jg_handle* h) {
+    if (!h->xl_ready) return JG_OK;
+    const int B = 8, L = 64;
+    std::vector<int32_t> ids((size_t)B * L);
+    uint32_t x = 0xC0FFEE11u;
+    for (auto& v : ids) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        v = 3 + (int32_t)(x % (uint32_t)(h->xl_vocab > 3 ? h->xl_vocab - 3 : 1));
+    }
+    for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 0; ids[(size_t)b * L + L - 1] = 2; }       // <s> ... </s>
+    int32_t* dids = nullptr;
+    float* out = nullptr;
+    HIPCHK(h, hipMalloc(&dids, ids.size() * sizeof(int32_t)));
+    if (hipMalloc(&out, (size_t)B * L * 768 * sizeof(float)) != hipSuccess) { (void)hipFree(dids); JG_FAIL(h, JG_ERR_HIP, "hipMalloc failed"); }
+    int rc = hipMemcpy(dids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess ? JG_OK : JG_ERR_HIP;
+    for (Lin* Ly : h->bc_layers) {
+        if (Ly->model != 3) continue;
+        if (hipMemsetAsync(Ly->mu, 0, sizeof(float) * Ly->K, h->stream) != hipSuccess) rc = JG_ERR_HIP;
+        Ly->mu_rows = 0;
+    }
+    if (rc == JG_OK) {
+        h->calib = true;
+        h->ws.reset();
+        rc = xlmr_encode_impl(h, dids, nullptr, B, L, out);
+        h->calib = false;
+    }
+    if (rc == JG_OK) rc = apply_bias_corrections(h, 4);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(dids);
+    (void)hipFree(out);
+    return rc;
+}
+
 // frames == nullptr: built-in deterministic calibration clips (uniform u8 noise, rows 0..109 zeroed like the
 // face-mask rectangle), so results do not depend on what the engine happens to see first.
 // models: bit 0 GestSync, bit 1 JEGAL -- only the bias-corrected layers of these models receive new corrections (the pass
@@ -1009,12 +1061,9 @@ int jegal_text_impl(jg_handle* h, const float* states, const float* mask, int B,
 // 12 heads of 64, intermediate 3072 (xlm-roberta-base); the vocabulary and position table sizes come from the tensors.
 int finalize_xlmr(jg_handle* h) {
     h->xl_ready = false;
-    (void)hipStreamSynchronize(h->stream);
-    for (void* p : h->wallocs_xl) (void)hipFree(p);
-    h->wallocs_xl.clear();
+    drop_model(h, h->wallocs_xl, 3);          // frees the previous weights, drops its bias-corrected layers from the calibration list
     h->xl_layers.clear();
     h->wallocs = &h->wallocs_xl;
-    h->cur_model = 3;
     constexpr int D = 768, DFF = 3072;
     const HostTensor* t = find(h, "xlmr.embeddings.word_embeddings.weight");
     if (!t || t->numel() % D) JG_FAIL(h, JG_ERR_WEIGHT, "missing or malformed 'xlmr.embeddings.word_embeddings.weight'");
@@ -1043,11 +1092,11 @@ int finalize_xlmr(jg_handle* h) {
             std::memcpy(&w[(size_t)i * D * D], wi->v.data(), sizeof(float) * D * D);
             std::memcpy(&b[(size_t)i * D], bi->v.data(), sizeof(float) * D);
         }
-        RET(pack_matrix(h, w, b, 3 * D, D, LK_CONTENT, &L->qkv));
-        RET(make_linear(h, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, &L->out, LK_CONTENT));
+        RET(pack_matrix(h, w, b, 3 * D, D, LK_XLMR, &L->qkv));
+        RET(make_linear(h, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, &L->out, LK_XLMR));
         RET(make_ln(h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", D, &L->n1));
-        RET(make_linear(h, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", DFF, D, &L->ff1, LK_CONTENT));
-        RET(make_linear(h, p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, &L->ff2, LK_CONTENT));
+        RET(make_linear(h, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", DFF, D, &L->ff1, LK_XLMR));
+        RET(make_linear(h, p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, &L->ff2, LK_XLMR));
         RET(make_ln(h, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", D, &L->n2));
     }
     h->xl_layers_n = nl;
@@ -1066,7 +1115,7 @@ int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int
     f16 *x16, *qkv, *att, *hid;
     RET(wsalloc(h, (size_t)M * D, &x32));
     RET(wsalloc(h, (size_t)M * D, &x16));
-    RET(wsalloc(h, (size_t)M * DFF, &t32));
+    RET(wsalloc(h, (size_t)M * D, &t32));
     RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
     RET(wsalloc(h, (size_t)M * D, &att));
     RET(wsalloc(h, (size_t)M * DFF, &hid));
@@ -1085,9 +1134,8 @@ int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int
         Epi r; r.res = x32; r.ldr = D; r.out32 = t32;
         RET(gemm(h, JG_ST_GEMM, att, D, M, Ly.out, r));
         RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, Ly.n1.w, Ly.n1.b, M, D, LN_STD, 0, x32, x16, h->stream); }));
-        Epi f; f.out32 = t32;
+        Epi f; f.relu = 2; f.out16 = hid;             // exact GELU in the GEMM epilogue (round 2: fp32 M x 3072 out + a separate kernel)
         RET(gemm(h, JG_ST_GEMM, x16, D, M, Ly.ff1, f));
-        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_gelu, t32, hid, (long)M * DFF, h->stream); }));
         RET(gemm(h, JG_ST_GEMM, hid, DFF, M, Ly.ff2, r));
         RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, Ly.n2.w, Ly.n2.b, M, D, LN_STD, 0, last ? out : x32, x16, h->stream); }));
     }
@@ -1242,6 +1290,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "gemm_tall_tile")) { o.gemm_tall_tile = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_small_tile")) { o.gemm_small_tile = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_big_tile")) { o.gemm_big_tile = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gemm_tile")) { o.gemm_tile = value; return JG_OK; }
     if (!std::strcmp(name, "gemm_counted")) { o.gemm_counted = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_persistent")) { o.gemm_persistent = value != 0; return JG_OK; }
     if (!std::strcmp(name, "gemm_stagger")) { o.gemm_stagger = value; return JG_OK; }
@@ -1309,6 +1358,7 @@ int jg_finalize_weights(jg_handle* h, int which) {
     // Built-in calibration only for the gesture models finalized by THIS call (XLM-R has no bias-corrected layers): the bias
     // corrections of the other model -- possibly from jg_calibrate_gesture on real clips -- are left as they are.
     if (h->precision == JG_PREC_FP16_BC && (which & 3)) RET(calibrate_impl(h, nullptr, JG_U8, 0, 0, which & 3));
+    if (h->precision == JG_PREC_FP16_BC && (which & 4)) RET(calibrate_xlmr(h));
     return JG_OK;
 }
 

@@ -174,6 +174,7 @@ struct EngineOpts {
     bool gemm_glds = true;               // LDS-DMA GEMM kernels (false: register-staged gemm_kernel everywhere)
     bool gemm_persistent = true;
     bool gemm_big_tile = true, gemm_small_tile = true, gemm_tall_tile = true;
+    int gemm_tile = 0;                   // plain GEMMs: 0 = pick by the cost estimate (launch_glds), 1 / 2 / 3 = force the 128x128 / 256x128 / 256x256 tile
     int gemm_counted = 1;                // counted s_waitcnt between a tile's epilogue stores and the next tile's first DMA
     int gemm_stagger = 0;                // 10-ns ticks per phase (0: default policy, -1: off)
     bool lanes_active = false;           // the launch is part of a two-lane batch (api.hip, run_in_lanes): the other lane's kernels already

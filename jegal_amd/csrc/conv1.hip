@@ -184,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     };
     auto no_fill = [](int, unsigned) {};
 
+    if (!(s_lo < r_hi && GX > 0)) return;      // a workgroup without a strip (launches of fewer strips than CUs): nothing to do, for either role
     if (use_skip) {
         unsigned* tab = reinterpret_cast<unsigned*>(smem + OFF_SKIP);
         for (int k = tid; k < MAX_WG_STRIPS; k += 512) {

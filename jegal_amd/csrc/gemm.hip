@@ -20,8 +20,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 JG_NS_BEGIN
+
+// epilogue activation (GemmArgs::relu): 0 none, 1 ReLU, 2 exact GELU 0.5 v (1 + erf(v / sqrt 2)) (XLM-RoBERTa's intermediate layer;
+// the conv instances are compiled with ReLU only)
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    if (act == 1) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (act == 2) {
+        v.x = 0.5f * v.x * (1.f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.f + erff(v.y * 0.70710678118654752f));
+        v.z = 0.5f * v.z * (1.f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
+    }
+    return v;
+}
 
 template <int WM, int WN, bool CONV, bool W2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -177,9 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                 const int rr = a.res_mod ? (m % a.res_mod) : m;
                 v += *reinterpret_cast<const f32x4*>(a.res + (long)rr * a.ldr + n);
             }
-            if (a.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
+            v = act4(v, CONV ? (a.relu != 0) : a.relu);
             if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + (long)m * a.ldc + n) = v;
             if (a.out16) {
                 f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
@@ -472,7 +483,11 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         __builtin_amdgcn_s_barrier();
         mark();     // 0: tile start (first k-tile landed)
         const int cn0 = n0, cm0 = m0;
-        const bool interior = cm0 + BM <= Mrows && cn0 + BN <= a.N;
+        // interior: the fast epilogues apply.  A tile that is only partial along M (the last row tile: M = 4800 is 18.75 tiles of
+        // 256 rows) takes them too, with its stores masked by row (m_full false): the generic per-element path below costs such a
+        // tile ~8 us, which is what a one-round launch of the small-M GEMMs then takes (tools/gemm_tiles.py).
+        const bool m_full = cm0 + BM <= Mrows;
+        const bool interior = cn0 + BN <= a.N;
         const int nb = cn0 + wn * 64 + fq * 4;
         const int mb = cm0 + wm * (16 * MI) + frow;
         // spreading the DMA pieces over the MFMA schedule, measured: -16 % on the 128x512 LN kernel (K = 2048), -5 % on the
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 // residual prefetch: issued under the last k-tile's MFMAs, consumed in the epilogue
 #pragma unroll
                 for (int j = 0; j < (PREFETCH_RES ? MI : 1); ++j) {
-                    const int m = mb + j * 16;
+                    const int m = mb + j * 16 < Mrows ? mb + j * 16 : Mrows - 1;      // rows past M: any valid row (their results are not stored)
                     const int rr = a.res_mod ? (m % a.res_mod) : m;
                     const float* rp = ares + (long)rr * a.ldr + nb;
 #pragma unroll
@@ -723,30 +738,32 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
             f16* ocol = a.out16 + cn0 + wn * 64 + (lane & 7) * 8;
+            auto store_rows = [&](auto masked_tag) __attribute__((always_inline)) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
+                for (int j = 0; j < MI; ++j) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 v = acc[i][j] * sc[i] + bi[i];
-                    if (a.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 v = acc[i][j] * sc[i] + bi[i];
+                        v = act4(v, CONV ? (a.relu != 0) : a.relu);
+                        f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                        *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
                     }
-                    f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                    *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
-                    const long orow = use_rtab ? rtab[j * 16 + h2 * 8 + (lane_t >> 3)] : orow_m + j * 16 + h2 * 8;
-                    __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(ocol + orow * a.ldc));
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const f16x8 o = *reinterpret_cast<const f16x8*>(tsc + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
+                        const long orow = use_rtab ? rtab[j * 16 + h2 * 8 + (lane_t >> 3)] : orow_m + j * 16 + h2 * 8;
+                        if (!MASKED || orow_m + j * 16 + h2 * 8 < Mrows) __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(ocol + orow * a.ldc));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            };
+            if (m_full) store_rows(std::false_type{}); else store_rows(std::true_type{});
         } else if (interior) {
             f32x4 sc[4], bi[4];
 #pragma unroll
@@ -762,34 +779,37 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
+            auto store_frag = [&](auto masked_tag) __attribute__((always_inline)) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const long mo = (use_rtab ? (long)rtab[j * 16 + (lane_t & 15)] : (long)(mb + j * 16)) * a.ldc + nb;
-                f32x4 rj[4];
-                if (!PREFETCH_RES) {
+                for (int j = 0; j < MI; ++j) {
+                    const long mo = (use_rtab ? (long)rtab[j * 16 + (lane_t & 15)] : (long)(mb + j * 16)) * a.ldc + nb;
+                    f32x4 rj[4];
+                    if (!PREFETCH_RES) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ares) {
-                        const int m = mb + j * 16;
-                        const int rr = a.res_mod ? (m % a.res_mod) : m;
-                        const float* rp = ares + (long)rr * a.ldr + nb;
+                        for (int i = 0; i < 4; ++i) rj[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ares) {
+                            const int m = !MASKED || mb + j * 16 < Mrows ? mb + j * 16 : Mrows - 1;
+                            const int rr = a.res_mod ? (m % a.res_mod) : m;
+                            const float* rp = ares + (long)rr * a.ldr + nb;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) rj[i] = *reinterpret_cast<const f32x4*>(rp + i * 16);
+                            for (int i = 0; i < 4; ++i) rj[i] = *reinterpret_cast<const f32x4*>(rp + i * 16);
+                        }
+                    }
+                    if (MASKED && mb + j * 16 >= Mrows) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 v = acc[i][j] * sc[i] + bi[i] + (PREFETCH_RES ? rs[i][j] : rj[i]);
+                        v = act4(v, CONV ? (a.relu != 0) : a.relu);
+                        if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = v;
+                        if (a.out16) {
+                            f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                            *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = h;
+                        }
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 v = acc[i][j] * sc[i] + bi[i] + (PREFETCH_RES ? rs[i][j] : rj[i]);
-                    if (a.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mo + i * 16) = v;
-                    if (a.out16) {
-                        f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                        *reinterpret_cast<f16x4*>(a.out16 + mo + i * 16) = h;
-                    }
-                }
-            }
+            };
+            if (m_full) store_frag(std::false_type{}); else store_frag(std::true_type{});
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -808,9 +828,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                         const int rr = a.res_mod ? (m % a.res_mod) : m;
                         v += *reinterpret_cast<const f32x4*>(ares + (long)rr * a.ldr + n);
                     }
-                    if (a.relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
+                    v = act4(v, CONV ? (a.relu != 0) : a.relu);
                     if (a.out32) *reinterpret_cast<f32x4*>(a.out32 + mf * a.ldc + n) = v;
                     if (a.out16) {
                         f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
@@ -821,7 +839,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
         mark();     // 3: epilogue issued
         if (nbid < 0) break;
-        pending = !(interior && counted_ok) ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
+        pending = !(interior && m_full && counted_ok) ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
     }
 }
 
@@ -945,6 +963,33 @@ static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_
             }
             return launch_glds_cfg<W2, true, 4, 4, 2, true>(a, o, s);
         }
+    }
+    if constexpr (!CONV) {
+        // Plain GEMMs: pick the tile by a cost estimate, rounds of one tile per CU x (k-tiles x time per k-tile + epilogue), with
+        // the per-tile figures measured on the box (tools/gemm_tiles.py; us, L2-resident operands): bigger tiles move fewer
+        // bytes per FLOP through the CU's LDS-DMA path but fill fewer CUs / leave emptier last rounds.  Every instance
+        // accumulates k in the same order, so the choice never changes a bit of the result.  (Round 2 took the 128x128 tile
+        // whenever fewer than 224 of the 256x256 tiles existed: M = 4800 x N = 2048 ran three rounds of small tiles instead of
+        // one round of 152 big ones, and XLM-R's N = 768 layers likewise.)
+        const int nk = (a.K + 63) / 64;
+        auto est = [&](int bm, int bn, double kt_us, double epi_us) {
+            const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
+            return (double)((tiles + o.num_cu - 1) / o.num_cu) * (nk * kt_us + epi_us);
+        };
+        const bool can_big = !W2 && o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0;
+        const double e_small = o.gemm_small_tile ? est(128, 128, W2 ? 1.25 : 0.95, 1.0) : 1e30;
+        const double e_mid = est(256, 128, W2 ? 1.6 : 1.2, 1.6);
+        const double e_big = can_big ? est(256, 256, 1.45, 2.7) : 1e30;
+        int pick = e_big <= e_mid && e_big <= e_small ? 3 : (e_mid <= e_small ? 2 : 1);
+        if (o.gemm_tile >= 1 && o.gemm_tile <= 3 && (o.gemm_tile != 3 || can_big)) pick = o.gemm_tile;
+        if (pick == 1) return launch_glds_cfg<W2, false, 2, 4, 2>(a, o, s);
+        if constexpr (!W2) {
+            if (pick == 3) {
+                if (a.K <= 1024) return launch_glds_cfg<false, false, 8, 2, 4, true>(a, o, s);       // short k loops: spread DMA issue
+                return launch_glds_cfg<false, false, 8, 2, 4>(a, o, s);
+            }
+        }
+        return launch_glds_cfg<W2, false, 4, 4, 2>(a, o, s);
     }
     if (o.gemm_small_tile && (tiles256 < 200 || tiles_big < 224)) return launch_glds_cfg<W2, CONV, 2, 4, 2>(a, o, s);
     if constexpr (!W2) {

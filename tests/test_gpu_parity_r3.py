@@ -122,3 +122,28 @@ def test_unpack_masked_rebuilds_the_dense_batch():
     dst = torch.full((F, 270, 480, 3), 7, dtype=torch.uint8, device="cuda")
     eng.unpack_masked(torch.from_numpy(packed).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(np.array(offs, np.int64)).cuda(), dst)
     assert np.array_equal(dst.cpu().numpy(), dense)
+
+
+@pytest.mark.parametrize("nclip,T", [(1, 8), (3, 8), (3, 10), (2, 8), (1, 5)])
+def test_conv1_launches_with_fewer_strips_than_cus(nclip, T):
+    """conv1_direct_kernel is a persistent kernel over nclip * (T + 4) * 5 column strips.  With fewer strips than CUs the strip
+    ranges of the eight XCDs leave some workgroups without a strip (60, 180, 210 strips: the last XCD's range is shorter than
+    its workgroup count).  Round 2 let those workgroups run through both roles with "harmless" frame loads; on unmasked clips
+    that faulted (a wild frame address, found in round 3 through the masked-upload test).  They now exit at once; this test
+    runs such launches on unmasked noise repeatedly and checks the result against the independent stack + implicit-GEMM path."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.gestsync import GestSync
+    eng = Engine.get("cuda:0")
+    GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    rng = np.random.default_rng(nclip * 100 + T)
+    frames = torch.from_numpy(rng.integers(1, 256, (nclip, T, 270, 480, 3), dtype=np.uint8)).cuda()
+    outs = [eng.debug_conv1_pool(frames, 4).clone() for _ in range(4)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    eng.set_option("conv1_direct", 0)
+    try:
+        alt = eng.debug_conv1_pool(frames, 4)
+    finally:
+        eng.set_option("conv1_direct", 1)
+    assert rel(outs[0].float(), alt.float()) < 3e-4
