@@ -1275,6 +1275,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "conv1_mfma16")) { o.conv1_mfma16 = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }

@@ -182,6 +182,7 @@ struct EngineOpts {
     unsigned long long* gemm_tl = nullptr;   // debug timeline buffer (option gemm_timeline)
     bool attn_mfma = true;
     bool conv1_zero_skip = true;
+    bool conv1_mfma16 = true;            // conv1_direct_kernel's MFMA waves on 16x16x32 MFMAs (false: 32x32x16, the round-1/2 form)
 };
 hipError_t engine_opts_init(EngineOpts& o, int device);      // queries the CU count, allocates the zero page (current device = `device`)
 void engine_opts_release(EngineOpts& o);

@@ -70,6 +70,67 @@ __global__ __launch_bounds__(256) void kchain16(float* out, int iters, const _Fl
     for (int i = 0; i < 4; ++i) s += c[0][i] + c[1][i] + c[2][i] + c[3][i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// the GEMM kernel's patterns: 16 accumulators acc[i][j], A fragment per i (4), B fragment per j (4), two k-steps (kk)
+//   ORDER 0: kk outer, j, i inner (gemm.hip round 1-3): every MFMA switches the accumulator, each accumulator gets one MFMA per kk
+//   ORDER 1: j, i, kk inner: two consecutive MFMAs per accumulator
+//   ORDER 2: one accumulator per (i, j) fed by 4 consecutive MFMAs (a K = 128 k-tile)
+template <int ORDER>
+__global__ __launch_bounds__(512) void kgemm16(float* out, int iters, const _Float16* src) {
+    f16x8 a[4][4], b[4][4];      // [kk][i], [kk][j]
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j) {
+            a[k][j] = *(const f16x8*)(src + ((threadIdx.x * 16 + k * 4 + j) * 8 & 32767));
+            b[k][j] = *(const f16x8*)(src + 32768 + ((threadIdx.x * 16 + k * 4 + j) * 8 & 16383));
+        }
+    f32x4 c[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) c[i][j] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        if (ORDER == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk][i], b[kk][j], c[i][j], 0, 0, 0);
+        } else if (ORDER == 1) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[k2 * 2 + kk][i], b[k2 * 2 + kk][j], c[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk][i], b[kk][j], c[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int ORDER> void rungemm16(const char* name, int wg) {
+    float* out; hipMalloc(&out, 1024 * 512 * 4);
+    _Float16* src; hipMalloc(&src, 65536 * 2);
+    static _Float16 hsrc[65536]; for (int i = 0; i < 65536; ++i) hsrc[i] = (_Float16)(((i * 2654435761u) >> 16 & 1023) / 512.0f - 1.0f);
+    hipMemcpy(src, hsrc, sizeof(hsrc), hipMemcpyHostToDevice);
+    const int iters = 40000, blocks = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kgemm16<ORDER>, dim3(blocks), dim3(wg), 0, 0, out, 1000, src);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kgemm16<ORDER>, dim3(blocks), dim3(wg), 0, 0, out, iters, src);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per = ms * 1e6 / (iters * 64.0) / (wg / 256);
+    printf("%-44s %8.3f ms  %.1f ns per MFMA per SIMD -> %.0f TFLOP/s\n", name, ms, per, 1024.0 * 16 * 16 * 32 * 2 / per / 1e3);
+}
 template <int NACC> void runchain16(const char* name) {
     float* out; hipMalloc(&out, 1024 * 256 * 4);
     _Float16* src; hipMalloc(&src, 65536 * 2);
@@ -101,6 +162,12 @@ template <int NACC> void runchain(const char* name) {
     printf("%-28s %8.3f ms  %.1f ns per MFMA per SIMD  (random data)\n", name, ms, ms * 1e6 / (iters * 8.0));
 }
 int main() {
+    rungemm16<0>("gemm pattern, acc switch every MFMA, 1 wave/SIMD", 256);
+    rungemm16<1>("gemm pattern, 2 MFMAs per acc, 1 wave/SIMD", 256);
+    rungemm16<2>("gemm pattern, 4 MFMAs per acc, 1 wave/SIMD", 256);
+    rungemm16<0>("gemm pattern, acc switch every MFMA, 2 waves/SIMD", 512);
+    rungemm16<1>("gemm pattern, 2 MFMAs per acc, 2 waves/SIMD", 512);
+    rungemm16<2>("gemm pattern, 4 MFMAs per acc, 2 waves/SIMD", 512);
     runchain16<1>("16x16x32 f16 1 acc chain");
     runchain16<2>("16x16x32 f16 2 acc chains");
     runchain16<4>("16x16x32 f16 4 acc chains");
