@@ -58,15 +58,20 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
 /* tuning / A-B switches, per handle (all default to the fast setting; results stay within the parity tolerance either way):
  *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel
  *   "conv1_zero_skip" 1: all-zero input bands (the face-mask rows) are skipped / run only the bias slots (bit-identical)
- *   "conv2_row_skip"  1: conv2 does not compute the leading output rows that the zero-band scan proves to be copies of one
- *                     row (their whole 5x5 window lies in conv1's constant region); they are copied instead (bit-identical)
+ *   "conv1_mfma16"    1: the fused conv1 kernel's MFMA waves run v_mfma_f32_16x16x32_f16 (0: 32x32x16, the round-1/2 form; the two
+ *                     differ in fp32 summation order only)
+ *   "conv2_row_skip"  1: conv2 .. conv5 do not compute the leading output rows of a POSITION that the zero-band scan proves to be
+ *                     independent of the position (their whole window lies in conv1's constant region); consumers read them from
+ *                     images computed once per weight load.  Per position: every position skips what its own five frames allow
+ *                     (bit-identical)
  *   "qkv0_linear"     1: the first transformer layer's qkv projection runs over the T+4 distinct conv positions and the 21
  *                     positional rows (linearity of W(conv + pe) + b); the attention kernel gathers and sums the rows
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
- *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16+8-bit token stream)
+ *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16 + fp8 token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
  *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
  *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_parity.py flips every one of them)
+ *   "gemm_tile"       0: plain GEMMs pick their tile by a measured cost estimate; 1 / 2 / 3: force 128x128 / 256x128 / 256x256 (bit-identical)
  *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and run the two parts concurrently on two internal
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.

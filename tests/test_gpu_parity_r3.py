@@ -147,3 +147,30 @@ def test_conv1_launches_with_fewer_strips_than_cus(nclip, T):
     finally:
         eng.set_option("conv1_direct", 1)
     assert rel(outs[0].float(), alt.float()) < 3e-4
+
+
+def test_gemm_tile_choice_never_changes_a_bit():
+    """launch_glds picks the plain GEMMs' tile (128x128 / 256x128 / 256x256) by a cost estimate; every instance accumulates k in
+    the same order, so forcing any of them (option gemm_tile) must reproduce the default bit for bit - on the gesture path (M-partial
+    last tiles: 3 x 60 x 21 tokens, 180 JEGAL tokens) and on the XLM-R front end."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    from jegal_amd.xlmr import XLMRoberta
+    eng = Engine(0)
+    GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    xl = XLMRoberta(engine=eng).load_state_dict(synth.xlmr_state_dict(layers=2))
+    frames = torch.from_numpy(synth.synth_frames(31, 3, 60)).cuda()
+    ids, mask = synth.xlmr_inputs(3, 24, 40)
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    base = eng.extract_gesture(frames).clone()
+    xbase = xl(ids_d, attention_mask=mask_d).last_hidden_state.clone()
+    for tile in (1, 2, 3):
+        eng.set_option("gemm_tile", tile)
+        try:
+            assert torch.equal(eng.extract_gesture(frames), base), f"gemm_tile={tile} changed the gesture embeddings"
+            assert torch.equal(xl(ids_d, attention_mask=mask_d).last_hidden_state, xbase), f"gemm_tile={tile} changed the XLM-R states"
+        finally:
+            eng.set_option("gemm_tile", 0)
+    eng.close()
