@@ -59,14 +59,17 @@ def load_traffic():
     """Per-launch HBM traffic of the dominant kernel from the committed counter passes (profiles/r2_pmc_summary.json,
     written by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
     command).  None when the summary is absent."""
-    p = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
-    if not os.path.exists(p):
-        return None, "no committed counter summary (profiles/r2_pmc_summary.json)"
+    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json"):          # the newest committed counter passes
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            break
+    else:
+        return None, "no committed counter summary (profiles/r3_pmc_summary.json)"
     d = json.load(open(p))
     k = d.get("conv1_direct_kernel")
     if not k:
-        return None, "conv1_direct_kernel missing from profiles/r2_pmc_summary.json"
-    return k["hbm_bytes_per_launch"], k.get("note", "")
+        return None, f"conv1_direct_kernel missing from profiles/{name}"
+    return k["hbm_bytes_per_launch"], f"profiles/{name}: " + k.get("note", "")
 
 
 def cpu_baseline(clips_u8, n_windows=96):
@@ -248,7 +251,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default)")
+    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default), 4 bf16 (reported mode: outside the 1e-3 contract)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
@@ -471,7 +474,7 @@ def main():
         res = {
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == 4 else "f16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic batch=32 gesture-only (GestSync conv + JEGAL gesture encoder), "
                                    "uint8 150x270x480x3 clips resident in HBM, seeded synthetic weights",
