@@ -938,8 +938,16 @@ static hipError_t launch_glds_ln(const GemmArgs& a, const EngineOpts& o, hipStre
         (void)hipStreamSynchronize(s);
         std::memset(o.gemm_tl, 0, 1024 * sizeof(unsigned long long));
     }
+    // De-phasing (see launch_glds_cfg), round 3: in this kernel every workgroup reaches its store / reload phase at the same moment
+    // and that phase is an HBM burst (100 MB per round in ~10 us) while the k loops leave HBM idle.  Four start phases spread it;
+    // the delay is free when the last round is less than half full, because the highest block ids - the ones delayed longest -
+    // run one tile fewer: out_proj 108 -> 94 us, linear2 265 -> 256 us at M = 100 800 (3.08 rounds), 52 -> 48 us at 1.15 rounds;
+    // with a nearly full last round it costs what it delays (1.92 rounds: 58 -> 61 us), so it is off there.
+    const int last_round = tiles % o.num_cu;
+    const int auto_stagger = tiles > o.num_cu && 2 * last_round < o.num_cu ? (a.K <= 1024 ? 500 : 1400) : 0;
+    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger : auto_stagger;
     hipLaunchKernelGGL((gemm_glds_kernel<false, CONV, 8, 1, 8, true>), dim3((unsigned)grid), dim3(512), lds, s, a, 1, tiles, o.zeros,
-                       o.gemm_counted | ((o.gemm_stagger > 0 ? o.gemm_stagger : 0) << 8), o.gemm_tl);
+                       o.gemm_counted | (stagger << 8), o.gemm_tl);
     if (o.gemm_tl) dump_timeline(o, s, "linear+LN");
     return hipGetLastError();
 }
