@@ -918,7 +918,13 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStr
     // once the outputs were nontemporal the epilogues became HBM-write-burst bound (every CU stores its 128 KB at the
     // same moment) and spreading them pays: qkv 157 -> 146 us.  Only for long plain GEMMs (>= 4 rounds); the LN-fused
     // and conv kernels and short launches measured neutral or slower.  Option gemm_stagger: ticks of 10 ns, -1 = off.
-    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger : (!CONV && tiles >= 4 * o.num_cu && !o.lanes_active ? 200 : 0);
+    // Round 3: the delay only pays when the last round is less than half full - the highest block ids, delayed longest, then run one
+    // tile fewer (ff0, 3.08 rounds: 79 -> 75 us; N = 1024, 6.16 rounds: 129 -> 117 us; qkv 9.23: 175 -> 170; with a nearly full last
+    // round it costs 2-3 %), short launches included (round 2: >= 4 rounds).  Inside the two-lane batches the plain GEMMs stay
+    // un-staggered: the other lane's kernels already spread the store bursts and the delay only costs (+0.8 % per step measured).
+    const int last_round = tiles % o.num_cu;
+    const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger
+                        : (!CONV && !o.lanes_active && tiles > o.num_cu && 2 * last_round < o.num_cu ? 300 : 0);
     hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
                        o.gemm_counted | (stagger << 8), o.gemm_tl);
     if (o.gemm_tl) dump_timeline(o, s, CONV ? "conv" : "linear");
