@@ -1018,18 +1018,17 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) 
     const ConvGeom g12 = geom(g9.OH, g9.OW, 256, 3, 3, 1, 3, 1, 1);
     const ConvGeom g15 = geom(g12.OH, g12.OW, 256, 1, 1, 1, 3, 0, 0);
     if (g15.OW != 1) JG_FAIL(h, JG_ERR_ARG, "audio CNN must reduce 80 mel bands to 1");
-    f16 *col, *c0, *c3, *c6, *c9, *c12, *c15;
+    f16 *c0, *c3, *c6, *c9, *c12, *c15;
     const long M0 = (long)B * Tm * F;
-    RET(wsalloc(h, (size_t)M0 * 32, &col));
     RET(wsalloc(h, (size_t)M0 * 32, &c0));
     RET(wsalloc(h, (size_t)B * g3.OH * g3.OW * 64, &c3));
     RET(wsalloc(h, (size_t)B * g6.OH * g6.OW * 128, &c6));
     RET(wsalloc(h, (size_t)B * g9.OH * g9.OW * 256, &c9));
     RET(wsalloc(h, (size_t)B * g12.OH * g12.OW * 256, &c12));
     RET(wsalloc(h, (size_t)B * g15.OH * 256, &c15));
-    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_im2col_mel, mel, B, Tm, F, col, h->stream); }));
+    // cnn.0 + BN + ReLU straight from the mel frames (round 2: im2col + a K = 32 GEMM on the register-staged kernel)
+    RET(timed(h, JG_ST_CONV, [&] { return LAUNCH(h, launch_audio_conv0, mel, B, Tm, F, h->a0.wh, h->a0.wl, h->a0.bias, c0, h->stream); }));
     Epi e; e.relu = 1;
-    e.out16 = c0; RET(gemm(h, JG_ST_CONV, col, 32, (int)M0, h->a0, e));
     e.out16 = c3; RET(gemm(h, JG_ST_CONV, c0, 0, B * g3.OH * g3.OW, h->a3, e, &g3));
     e.out16 = c6; RET(gemm(h, JG_ST_CONV, c3, 0, B * g6.OH * g6.OW, h->a6, e, &g6));
     e.out16 = c9; RET(gemm(h, JG_ST_CONV, c6, 0, B * g9.OH * g9.OW, h->a9, e, &g9));

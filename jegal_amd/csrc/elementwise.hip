@@ -354,36 +354,60 @@ hipError_t launch_l2norm(const float* in, float* out, int rows, int D, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------
-// First audio conv (jegal.py:42, Conv2d(1,32,5,pad 2)) as im2col: out[(b,t,f)][32] = 25 taps + 7 zeros.
-__global__ void im2col_mel_kernel(const float* __restrict__ mel, int B, int Tm, int F, f16* __restrict__ out) {
-    const long total = (long)B * Tm * F;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int f = idx % F;
-        long r = idx / F;
-        const int t = r % Tm;
-        const int b = r / Tm;
-        f16 v[32];
-#pragma unroll
-        for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 5; ++kw) {
-                const int tt = t + kh - 2, ff = f + kw - 2;
-                float x = 0.f;
-                if (tt >= 0 && tt < Tm && ff >= 0 && ff < F) x = mel[((long)b * Tm + tt) * F + ff];
-                v[kh * 5 + kw] = (f16)x;
-            }
-#pragma unroll
-        for (int e = 25; e < 32; ++e) v[e] = (f16)0.f;
-        uint4* d = reinterpret_cast<uint4*>(out + idx * 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<uint4*>(&v[q * 8]);
+// First audio conv (jegal.py:42, Conv2d(1,32,5,pad 2) + BN + ReLU) directly (round 3; rounds 1-2: an im2col kernel + a register-staged
+// K = 32 GEMM, 0.24 ms of the 0.64 ms audio CNN at B = 64; now 0.10 ms): out[(b,t,f)][32] = relu(sum_taps x16 * w16 + bias), the same operands the GEMM saw (mel and the BN-folded weights
+// rounded to the 16-bit operand type, fp32 accumulation; only the summation order differs).  One thread per output pixel: the
+// 5 x 5 neighbourhood comes from a mel tile in LDS, the 25 x 32 weights are wave-uniform (fp32 copy in LDS, broadcast reads),
+// 800 FMAs per pixel, one 64-byte NHWC store.  W2 modes carry the lo part of the weights in the same fp32 copy.
+__global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restrict__ mel, int B, int Tm, int F, const f16* __restrict__ wh,
+                                                          const f16* __restrict__ wl, const float* __restrict__ bias, f16* __restrict__ out) {
+    constexpr int TR = 3, FW_MAX = 84;                   // 3 output rows x F (<= 80) per block: (TR + 4) x (F + 4) mel values staged
+    __shared__ float sm[(TR + 4) * FW_MAX];
+    __shared__ float sw[25 * 32];
+    __shared__ float sb[32];
+    const int tid = threadIdx.x;
+    const int tiles_t = (Tm + TR - 1) / TR;
+    const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x - b * tiles_t) * TR;
+    for (int i = tid; i < 25 * 32; i += 256) {
+        const int tap = i >> 5, oc = i & 31;
+        sw[i] = (float)wh[oc * 32 + tap] + (wl ? (float)wl[oc * 32 + tap] : 0.f);
     }
+    if (tid < 32) sb[tid] = bias[tid];
+    const int FW = F + 4;
+    for (int i = tid; i < (TR + 4) * FW; i += 256) {
+        const int r = i / FW, c = i - r * FW;
+        const int tt = t0 + r - 2, ff = c - 2;
+        float x = 0.f;
+        if (tt >= 0 && tt < Tm && ff >= 0 && ff < F) x = mel[((long)b * Tm + tt) * F + ff];
+        sm[r * FW_MAX + c] = (float)(f16)x;             // the operand rounding of the GEMM path
+    }
+    __syncthreads();
+    const int r = tid / F, f = tid - r * F;
+    if (r >= TR || t0 + r >= Tm) return;
+    float acc[32];
+#pragma unroll
+    for (int oc = 0; oc < 32; ++oc) acc[oc] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+            const float x = sm[(r + kh) * FW_MAX + f + kw];
+            const float* w = sw + (kh * 5 + kw) * 32;
+#pragma unroll
+            for (int oc = 0; oc < 32; ++oc) acc[oc] = __builtin_fmaf(x, w[oc], acc[oc]);
+        }
+    f16 o[32];
+#pragma unroll
+    for (int oc = 0; oc < 32; ++oc) o[oc] = (f16)fmaxf(acc[oc] + sb[oc], 0.f);
+    uint4* d = reinterpret_cast<uint4*>(out + (((long)b * Tm + t0 + r) * F + f) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<uint4*>(&o[q * 8]);
 }
 
-hipError_t launch_im2col_mel(const float* mel, int B, int Tm, int F, f16* out, hipStream_t s) {
-    const long total = (long)B * Tm * F;
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(im2col_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mel, B, Tm, F, out);
+hipError_t launch_audio_conv0(const float* mel, int B, int Tm, int F, const f16* wh, const f16* wl, const float* bias, f16* out, hipStream_t s) {
+    if (B <= 0 || Tm <= 0) return hipSuccess;
+    if (F < 1 || F > 80 || 3 * F > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(audio_conv0_kernel, dim3((unsigned)(B * ((Tm + 2) / 3))), dim3(256), 0, s, mel, B, Tm, F, wh, wl, bias, out);
     return hipGetLastError();
 }
 

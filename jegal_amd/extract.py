@@ -103,11 +103,12 @@ FRAME_BYTES = 270 * FRAME_ROW_BYTES
 class _MaskedPacker:
     """Host side of the masked upload: the kept rows (>= row0) of every frame of a batch, back to back in a pinned buffer."""
 
-    def __init__(self, batch, T):
+    def __init__(self, batch, T, pinned=True):
         self.batch, self.T = batch, T
-        self.buf = torch.empty((batch * T * FRAME_BYTES,), dtype=torch.uint8).pin_memory()
-        self.row0 = torch.zeros((batch * T,), dtype=torch.int32).pin_memory()
-        self.offs = torch.zeros((batch * T,), dtype=torch.int64).pin_memory()
+        pin = (lambda t: t.pin_memory()) if pinned else (lambda t: t)        # pinned=False: host-logic tests without a GPU
+        self.buf = pin(torch.empty((batch * T * FRAME_BYTES,), dtype=torch.uint8))
+        self.row0 = pin(torch.zeros((batch * T,), dtype=torch.int32))
+        self.offs = pin(torch.zeros((batch * T,), dtype=torch.int64))
         self.reset()
 
     def reset(self):

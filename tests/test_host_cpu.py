@@ -212,3 +212,29 @@ def test_cli_drivers_pick_the_calibration_free_mode_for_real_checkpoints():
     assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 1
     assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/gestsync.pth"]) == 3
     assert pick_precision(NS(precision=0, calibrate_frames=None), ["/ckpt/jegal.pth"]) == 0
+
+
+def test_masked_packer_layout():
+    """Host side of the masked upload (jegal_amd.extract._MaskedPacker): the rows >= row0 of every frame back to back, row0 and byte
+    offsets per frame -- exactly what jg_unpack_masked consumes (include/jegal_hip.h); uniform and per-frame mask heights."""
+    from jegal_amd.extract import _MaskedPacker, FRAME_ROW_BYTES
+    T = 3
+    rng = np.random.default_rng(0)
+    clips = rng.integers(1, 256, (2, T, 270, 480, 3), dtype=np.uint8)
+    pk = _MaskedPacker(2, T, pinned=False)
+    pk.add(clips[0], 110)
+    pk.add(clips[1], np.array([0, 270, 135]))
+    assert pk.n == 2
+    row0, offs, buf = pk.row0.numpy(), pk.offs.numpy(), pk.buf.numpy()
+    assert row0.tolist() == [110, 110, 110, 0, 270, 135]
+    kept = (270 - row0.astype(np.int64)) * FRAME_ROW_BYTES
+    assert offs.tolist() == np.concatenate(([0], np.cumsum(kept)[:-1])).tolist() and pk.used == int(kept.sum())
+    assert all(o % 16 == 0 for o in offs)
+    for f in range(2 * T):
+        b, t = divmod(f, T)
+        assert np.array_equal(buf[offs[f]:offs[f] + kept[f]], clips[b, t, row0[f]:].reshape(-1))
+    with pytest.raises(ValueError):
+        pk.add(clips[0], 110)                       # batch is full
+    pk.reset()
+    with pytest.raises(ValueError):
+        pk.add(clips[0], 271)
