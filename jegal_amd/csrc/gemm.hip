@@ -598,8 +598,10 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         if constexpr (CONV) {
             if (use_rtab) {
                 const int wrow0 = cm0 + wm * WROWS;
-                if (WROWS >= 64 || lane_t < WROWS) rtab[lane_t] = rmap[wrow0 + lane_t] & 0xffffff;
-                if (WROWS > 64) rtab[64 + lane_t] = rmap[wrow0 + 64 + lane_t] & 0xffffff;
+                // (rows past Mrows of an M-partial tile: clamped -- their stores are masked, but the read must stay inside the map)
+                const int i0 = wrow0 + lane_t < Mrows ? wrow0 + lane_t : Mrows - 1, i1 = wrow0 + 64 + lane_t < Mrows ? wrow0 + 64 + lane_t : Mrows - 1;
+                if (WROWS >= 64 || lane_t < WROWS) rtab[lane_t] = rmap[i0] & 0xffffff;
+                if (WROWS > 64) rtab[64 + lane_t] = rmap[i1] & 0xffffff;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
