@@ -49,8 +49,9 @@ struct Conv1Args {
     float invP;           // 1/P for the position -> (clip, frame) split
     unsigned long long* tl;   // debug timeline (env JG_CONV1_TL): 100 MHz stamps of workgroup 0, waves 0 and 4
     int zskip;            // 1: all-zero input tiles (the face-mask rows) run only the two bias slots
-    const unsigned* zmask;    // [nclip*P] per POSITION: bit rt = tile rt of the position's 5 strips is skipped outright
-                              // (conv1_zero_scan_kernel + conv1_skip_mask_kernel); nullptr: no tile is skipped
+    const unsigned* zmask;    // [nclip*P] per POSITION: bit rt = input band rt is zero in all five frames of the position
+                              // (conv1_zero_scan_kernel + conv1_skip_mask_kernel); tile rt is skipped outright when bits rt and
+                              // rt-1 are set; nullptr: no pre-scan, zero tiles are detected from the loaded bytes
     const f16* zconst;        // [64] relu(bias) per channel as fp16: the value of every conv1 output whose patch is all zero
     int fill_partial;         // 1: conv2 honours the per-position row skip (common.h, ConvGeom::rowmap): it reads pooled rows >= 2 s2 of a
                               // position only (s2 from the position's own skip mask), and the constant fill leaves the rows above unwritten
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         int strip, rt;
         int k;              // strip = s_lo + k * GX: index into the workgroup's skip table in LDS
         unsigned skip;      // bit rt: tile rt of `strip` is skipped
+        unsigned z;         // bit rt: input band rt is zero in all five frames of the strip's position (the pre-scan's knowledge)
         bool done;
     };
     // strip -> (position nf, column tile j, clip b, padded-clip position p)
@@ -160,9 +162,11 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
     // walks would put an s_waitcnt vmcnt(0) -- hipcc cannot count across the walks' loops -- behind every batch of frame loads.
     const unsigned* skip_tab = reinterpret_cast<const unsigned*>(smem + OFF_SKIP);
     const bool use_skip = a.zmask != nullptr;
-    auto strip_skip = [&](int k) -> unsigned {
+    // the table holds the positions' zero-band masks z; a tile is skipped when its band and the band above are zero
+    auto strip_zero = [&](int k) -> unsigned {
         return use_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)skip_tab[k]) : 0u;
     };
+    auto skip_of = [](unsigned z) -> unsigned { return z & ((z << 1) | 1u); };
     // on_strip(strip, skip) is called once for every strip the walk enters (the pool walk fills the skipped tiles there)
     auto walk_next = [&](Walk& q, auto&& on_strip) {
         if (q.done) return;
@@ -172,16 +176,18 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 q.strip += GX;
                 ++q.k;
                 if (q.strip >= r_hi) { q.done = true; return; }
-                q.skip = strip_skip(q.k);
+                q.z = strip_zero(q.k);
+                q.skip = skip_of(q.z);
                 on_strip(q.strip, q.skip);
             }
             if (!((q.skip >> q.rt) & 1u)) return;
         }
     };
     auto walk_first = [&](auto&& on_strip) -> Walk {
-        Walk q = {s_lo, -1, 0, 0u, !(s_lo < r_hi && GX > 0)};
+        Walk q = {s_lo, -1, 0, 0u, 0u, !(s_lo < r_hi && GX > 0)};
         if (q.done) return q;
-        q.skip = strip_skip(0);
+        q.z = strip_zero(0);
+        q.skip = skip_of(q.z);
         on_strip(q.strip, q.skip);
         walk_next(q, on_strip);
         return q;
@@ -289,13 +295,21 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         };
         bool zero_image[2] = {false, false};       // this wave's part of tile buffer b currently holds an all-zero tile
         int* flags = reinterpret_cast<int*>(smem + OFF_INIT);
-        auto cvt_write = [&](const C1Regs& R, char* buf, int slot) {
-            uint32_t nz = 0;
+        // known_zero: the pre-scan found this tile's input band zero in all five frames (Walk::z) -- then nothing needs to be
+        // looked at here.  Without the scan's table (zmask == nullptr) the loaded bytes are OR-ed as in round 1: 30 VALU
+        // instructions + a ballot per tile on the role that sets the tile time.
+        auto cvt_write = [&](const C1Regs& R, char* buf, int slot, bool known_zero) {
+            bool any;
+            if (use_skip) {
+                any = !known_zero;
+            } else {
+                uint32_t nz = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int dt = 0; dt < 5; ++dt) nz |= R.w[u][dt][0] | R.w[u][dt][1] | R.w[u][dt][2];
-            const bool any = !a.zskip || __builtin_amdgcn_ballot_w64(nz != 0) != 0;       // wave-uniform
+                    for (int dt = 0; dt < 5; ++dt) nz |= R.w[u][dt][0] | R.w[u][dt][1] | R.w[u][dt][2];
+                any = !a.zskip || __builtin_amdgcn_ballot_w64(nz != 0) != 0;       // wave-uniform
+            }
             if (lane == 0) flags[slot * 4 + (wave - 4)] = any ? 1 : 0;
             if (!any && zero_image[slot]) return;
             zero_image[slot] = !any;
@@ -428,14 +442,14 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         // its last positions, kept in a small history: hA = tile t+2, hB = t+1 (image written this iteration), hC = t (the
         // MFMA waves' tile), hD = t-1 (pooled this iteration).  Entering a strip (on_strip) sets up its frame addressing and
         // fills its skipped tiles with the constant -- those stores touch no other tile's rows, so they can go at any time.
-        struct Hist { int strip, rt; unsigned skip; bool done; };
+        struct Hist { int strip, rt; unsigned skip; bool zero; bool done; };      // zero: the tile's band is zero in all five frames
         auto on_strip = [&](int strip, unsigned skip) {
             strip_setup(strip);
             fill_skipped(strip, skip);
         };
         Walk qi = walk_first(on_strip);
-        auto hist = [](const Walk& q) { return Hist{q.strip, q.rt, q.skip, q.done}; };
-        const Hist none = {0, 0, 0u, true};
+        auto hist = [](const Walk& q) { return Hist{q.strip, q.rt, q.skip, q.rt >= 0 && ((q.z >> q.rt) & 1u) != 0, q.done}; };
+        const Hist none = {0, 0, 0u, false, true};
         Hist hA = none, hB = none, hC = none, hD = none;
         // issue the frame loads of the walk's tile and advance it.  The loads are UNCONDITIONAL (past the end the last tile is
         // simply loaded again: under an `if` the loaded registers become a phi with their old values and hipcc resolves it with
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
         issue_next(RA);                         // tile 0 (or nothing: the loads are harmless)
         if (any_tile) {
             wait_frames(RA, 0);
-            cvt_write(RA, smem, 0);
+            cvt_write(RA, smem, 0, hA.zero);
         }
         issue_next(RB);                         // tile 1
         issue_next(RA);                         // tile 2        now hA = 2, hB = 1, hC = 0
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const bool zc0 = tile_is_zero(t);          // before cvt_write reuses the other slot; this slot is rewritten at t+1
             if (ltid == 0) live[(t + 1) & 1] = hB.done ? 0 : 1;
             wait_frames(RB, (t >= 2 && !dbg) ? 2 : 1);
-            if (!hB.done && !(dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (!hB.done && !(dbg & 8)) cvt_write(RB, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1, hB.zero);
             mark();
             if (t > 0 && !(dbg & 4)) pool_step(t - 1);          // hD = tile t-1; its stores go BEFORE the loads (wait_frames)
             mark();
@@ -511,7 +525,7 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
             const bool zc1 = tile_is_zero(t);
             if (ltid == 0) live[(t + 1) & 1] = hB.done ? 0 : 1;
             wait_frames(RA, (t >= 2 && !dbg) ? 2 : 1);
-            if (!hB.done && !(dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1);
+            if (!hB.done && !(dbg & 8)) cvt_write(RA, smem + ((t + 1) & 1) * TILE_BYTES, (t + 1) & 1, hB.zero);
             mark();
             if (!(dbg & 4)) pool_step(t - 1);
             mark();
@@ -830,7 +844,7 @@ __global__ void conv1_skip_mask_kernel(const unsigned* __restrict__ fz, int ncli
             z &= fz[b * T + f];
         }
         const unsigned sk = z & ((z << 1) | 1u);
-        skip[nf] = sk;
+        skip[nf] = z;                                    // the kernel derives sk itself and uses z for the tiles that still run
         rs = conv1_s2_of_mask(sk);
         s2[nf] = rs;
     }
