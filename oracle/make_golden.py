@@ -111,13 +111,14 @@ def golden_asd(ea):
     print("asd golden: correct", counts, "of", n)
 
 
-def golden_xlmr():
+def golden_xlmr(layers_arg=None, fname="xlmr.npz", seed=9011, B=3, L=24):
     """(vii) XLM-RoBERTa text front end: the third-party model itself -- transformers.XLMRobertaModel with the
     xlm-roberta-base architecture (reduced vocabulary / depth, the released checkpoint is not available offline), strict-loaded
-    with the seeded weights of synth.xlmr_state_dict -- run as the reference's call site does (jegal.py:126-127)."""
+    with the seeded weights of synth.xlmr_state_dict -- run as the reference's call site does (jegal.py:126-127).
+    xlmr.npz: 4 layers (round 2); xlmr12.npz: the full depth of xlm-roberta-base, 12 layers, 514 positions (round 3)."""
     import transformers
     from transformers import XLMRobertaConfig, XLMRobertaModel
-    sd = synth.xlmr_state_dict()
+    sd = synth.xlmr_state_dict() if layers_arg is None else synth.xlmr_state_dict(layers=layers_arg)
     layers = 0
     while f"encoder.layer.{layers}.attention.self.query.weight" in sd:
         layers += 1
@@ -129,13 +130,13 @@ def golden_xlmr():
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     missing = [k for k in missing if "position_ids" not in k and "token_type_ids" not in k]      # registered buffers, not weights
     assert not missing and not unexpected, (missing, unexpected)
-    ids, mask = synth.xlmr_inputs(9011, 3, 24)
+    ids, mask = synth.xlmr_inputs(seed, B, L)
     with torch.no_grad():
         out = model(torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long()).last_hidden_state
         out_nomask = model(torch.from_numpy(ids[:1]).long()).last_hidden_state
-    np.savez_compressed(os.path.join(OUT, "xlmr.npz"), seed=9011, input_ids=ids, attention_mask=mask, last_hidden_state=out.numpy(),
+    np.savez_compressed(os.path.join(OUT, fname), seed=seed, layers=layers, input_ids=ids, attention_mask=mask, last_hidden_state=out.numpy(),
                         last_hidden_state_nomask=out_nomask.numpy(), transformers_version=transformers.__version__)
-    print("xlmr golden:", out.shape, "transformers", transformers.__version__)
+    print("xlmr golden", fname, ":", out.shape, layers, "layers, transformers", transformers.__version__)
 
 
 def main():
@@ -146,6 +147,7 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         torch.manual_seed(0)
         golden_xlmr()
+        golden_xlmr(layers_arg=12, fname="xlmr12.npz", seed=9012, B=2, L=40)
         return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)

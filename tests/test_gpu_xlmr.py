@@ -121,3 +121,21 @@ def test_text_to_content_embedding_end_to_end(xlmr):
     e = rel(c.cpu(), c_ref.cpu())
     print("content embeddings, engine XLM-R vs oracle XLM-R hidden states: rel-L2 %.3e" % e)
     assert e < TOL
+
+
+def test_xlmr_12_layers_matches_transformers_golden(golden_dir):
+    """the 12-layer model was only checked by a tool.  Full depth of xlm-roberta-base against transformers itself
+    (tests/golden/xlmr12.npz, generated by oracle/make_golden.py xlmr), default precision mode (bias-corrected single-fp16 weights,
+    calibrated on built-in token ids)."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.xlmr import XLMRoberta
+    g = np.load(os.path.join(golden_dir, "xlmr12.npz"))
+    eng = Engine(0)
+    m = XLMRoberta(engine=eng).load_state_dict(synth.xlmr_state_dict(layers=12))
+    out = m(torch.from_numpy(g["input_ids"]).cuda(), attention_mask=torch.from_numpy(g["attention_mask"]).cuda()).last_hidden_state.cpu()
+    ref = torch.from_numpy(g["last_hidden_state"])
+    mk = torch.from_numpy(g["attention_mask"]).bool()
+    e = rel(out[mk], ref[mk])
+    print("xlmr 12 layers vs transformers golden: rel-L2 %.3e, max-abs %.3e" % (e, float((out[mk] - ref[mk]).abs().max())))
+    eng.close()
+    assert e < TOL

@@ -165,3 +165,14 @@ def test_xlmr_oracle_matches_transformers(golden_dir):
         out1 = O.xlmr_forward(sd, g["input_ids"][:1]).numpy()
     assert np.abs(out - g["last_hidden_state"]).max() < 2e-5
     assert np.abs(out1 - g["last_hidden_state_nomask"]).max() < 2e-5
+
+
+def test_xlmr_oracle_matches_transformers_12_layers(golden_dir):
+    """The full depth of xlm-roberta-base (12 layers, 514 positions; reduced vocabulary): tests/golden/xlmr12.npz, round 3."""
+    g = np.load(os.path.join(golden_dir, "xlmr12.npz"))
+    assert int(g["layers"]) == 12
+    sd = synth.xlmr_state_dict(layers=12)
+    with torch.no_grad():
+        out = O.xlmr_forward(sd, g["input_ids"], g["attention_mask"]).numpy()
+    m = g["attention_mask"].astype(bool)
+    assert np.abs(out[m] - g["last_hidden_state"][m]).max() < 5e-5
