@@ -121,6 +121,16 @@ def test_text_to_content_embedding_end_to_end(xlmr):
     e = rel(c.cpu(), c_ref.cpu())
     print("content embeddings, engine XLM-R vs oracle XLM-R hidden states: rel-L2 %.3e" % e)
     assert e < TOL
+    # and the whole chain against the ORACLE end to end (round 3: the comparison above shares the engine's JEGAL half): fp32
+    # restatement of XLM-R -> fp32 restatement of JEGAL text encoder + word pooling + fusion / align, per clip over its real words
+    jsd = O.tensors(synth.jegal_state_dict())
+    with torch.no_grad():
+        c_orc = O.jegal_forward_inference(jsd, text=(states, pack[1], pack[2], pack[3], pack[4]))
+    nwords = [len(t.split(" ")) for t in text]
+    for b, w in enumerate(nwords):
+        eb = rel(xlmr.engine.l2norm(c[b, :w]).cpu(), O.l2_normalize(c_orc[b, :w]))
+        print("clip %d (%d words): engine chain vs oracle chain rel-L2 %.3e" % (b, w, eb))
+        assert eb < TOL
 
 
 def test_xlmr_12_layers_matches_transformers_golden(golden_dir):
