@@ -53,7 +53,8 @@ const char* jg_last_error(jg_handle* h);
  * stream.  Until this is called the handle uses a private non-blocking stream. */
 int jg_set_stream(jg_handle* h, void* hip_stream);
 int jg_set_precision(jg_handle* h, int mode);
-/* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds workspace */
+/* clips (or 25-frame windows / 8) of the GestSync conv stack processed per pass; bounds the workspace (default 32: ~14 GB per lane
+ * for 150-frame clips - fewer, larger launches are what the 288 GB of the part are for; lower it for long clips on a shared GPU) */
 int jg_set_chunk(jg_handle* h, int clips_per_chunk);
 /* tuning / A-B switches, per handle (all default to the fast setting; results stay within the parity tolerance either way):
  *   "conv1_direct"    1: fused u8 conv1+pool kernel, 0: temporal stack + implicit GEMM + pool kernel

@@ -100,7 +100,7 @@ struct jg_handle {
     bool calib = false;            // calibration pass in progress (bc layers use hi+lo and record input means)
     bool gs_calibrated = false, jg_calibrated = false;
     std::vector<Lin*> bc_layers;   // bias-corrected layers of both models (entries of a model are dropped on its re-finalize)
-    int chunk = 8;
+    int chunk = 32;                // clips per GestSync pass: ~14 GB of workspace per lane at 150 frames; 288 GB of HBM make the whole BASELINE batch one pass
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)

@@ -341,7 +341,7 @@ def test_batch32_properties(engine, models):
     assert rel(solo[0], a[5]) < 1e-5
     engine.set_chunk(3)
     c = engine.extract_gesture(frames[:7])
-    engine.set_chunk(8)
+    engine.set_chunk(32)
     assert rel(c, a[:7]) < 1e-5
 
 

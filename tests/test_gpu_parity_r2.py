@@ -353,7 +353,7 @@ def test_bias_correction_with_mismatched_calibration(option_case):
     e.set_chunk(2)                                   # calibration batch larger than a chunk: means accumulate over chunks
     e.calibrate(big)
     errs["chunked"] = rel(e.extract_gesture(frames).cpu(), ref)
-    e.set_chunk(8)
+    e.set_chunk(32)
     e.calibrate(big)
     errs["unchunked"] = rel(e.extract_gesture(frames).cpu(), ref)
     e.close()
