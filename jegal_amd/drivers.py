@@ -87,7 +87,7 @@ def cmd_extract_gestsync_feats(argv):
     p.add_argument("--frames_dir", required=True, help="<vid>/<track>.npy masked uint8 crops (T,270,480,3)")
     p.add_argument("--result_dir", required=True)
     p.add_argument("--batch_size", type=int, default=48, help="accepted for compatibility; windows are never materialised")
-    p.add_argument("--clips_per_batch", type=int, default=8)
+    p.add_argument("--clips_per_batch", type=int, default=16, help="clips of similar length processed per engine call (padded to the longest with its last frame: exact)")
     p.add_argument("--rank", type=int, default=None)
     p.add_argument("--nshard", type=int, default=None)
     _add_precision_args(p)
@@ -104,18 +104,41 @@ def cmd_extract_gestsync_feats(argv):
             saved += 1
             continue
         todo.append((f, out))
-    for f, out in todo:
+    # Clips of different lengths go through the engine in batches: a clip padded with copies of its LAST frame gives, for its own
+    # T frames, exactly the windows of the reference's edge padding (inference_embs.py:283 replicates the last frame 12 times;
+    # window t only reaches frame t+12) - so a batch is padded to its longest clip, the first T_i rows of clip i are kept, and
+    # the GEMMs see clips_per_batch clips at once instead of one.  Files are sorted by length to keep the padding small.
+    def clip_len(f):
         try:
-            frames = np.load(f)
-            if frames.ndim != 4 or frames.shape[1:] != (270, 480, 3):
-                raise ValueError("expected (T,270,480,3), got %s" % (frames.shape,))
-            feats = gs.extract_clip_feats(torch.from_numpy(frames).to(eng.device))[0]
-            os.makedirs(os.path.dirname(out), exist_ok=True)
-            np.save(out, feats.cpu().numpy())
-            saved += 1
-        except Exception as e:                       # per-file try/except as the reference (:347-351)
-            err += 1
-            print("Error: ", e, " | Video file: ", f)
+            shp = np.load(f, mmap_mode="r").shape
+            return shp[0] if len(shp) == 4 and tuple(shp[1:]) == (270, 480, 3) else -1
+        except Exception:
+            return -1
+    sized = sorted(((clip_len(f), f, out) for f, out in todo), key=lambda x: x[0])
+    for T_bad, f, _ in [x for x in sized if x[0] <= 0]:
+        err += 1
+        print("Error: ", "expected a (T,270,480,3) uint8 .npy", " | Video file: ", f)
+    sized = [x for x in sized if x[0] > 0]
+    nb = max(1, args.clips_per_batch)
+    for s0 in range(0, len(sized), nb):
+        group = sized[s0:s0 + nb]
+        try:
+            Tmax = max(t for t, _, _ in group)
+            batch = np.empty((len(group), Tmax, 270, 480, 3), np.uint8)
+            for i, (t, f, _) in enumerate(group):
+                fr = np.load(f)
+                if fr.dtype != np.uint8:
+                    raise ValueError("expected uint8 crops, got %s in %s" % (fr.dtype, f))
+                batch[i, :t] = fr
+                batch[i, t:] = fr[t - 1]
+            feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device)).cpu().numpy()
+            for i, (t, f, out) in enumerate(group):
+                os.makedirs(os.path.dirname(out), exist_ok=True)
+                np.save(out, feats[i, :t])
+                saved += 1
+        except Exception as e:                       # per-batch try/except (the reference: per file, :347-351)
+            err += len(group)
+            print("Error: ", e, " | Video files: ", [f for _, f, _ in group])
     print("No of files saved = {} | Err = {}".format(saved, err))
     return 0
 

@@ -157,3 +157,31 @@ def test_mask_resize_matches_oracle(H, W):
     got2 = load_rgb_masked_frames(eng, frames, kp).cpu().numpy()
     my = int(0.25 * H) + 15
     np.testing.assert_array_equal(got2, O.mask_resize_frames(frames, [-1, my, my, -1]))
+
+
+def test_ragged_batches_by_last_frame_padding_are_exact():
+    """The feature-extraction driver batches clips of different lengths by padding each with copies of its last frame
+    (inference_embs.py:283 edge-pads with the last frame, and window t only reaches frame t+12): the first T_i feature rows of a
+    padded clip are those of the clip itself.  Bit for bit between two paddings of different length (same kernel path, nothing of
+    the padding may leak into the kept rows); against the clip run alone within the path-to-path noise (a single short clip takes
+    the unfused fp32-stream transformer, the batch the fused one: both are within 1e-3 of the fp32 reference, 4.5e-4 of each other)."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.gestsync import GestSync
+    eng = Engine.get("cuda:0")
+    gs = GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    lens = [17, 30, 26]
+    clips = [synth.synth_frames(40 + i, 1, t)[0] for i, t in enumerate(lens)]
+
+    def padded(Tpad):
+        batch = np.empty((3, Tpad, 270, 480, 3), np.uint8)
+        for i, c in enumerate(clips):
+            batch[i, :lens[i]] = c
+            batch[i, lens[i]:] = c[-1]
+        return gs.extract_clip_feats(torch.from_numpy(batch).cuda()).cpu()
+
+    out, out_longer = padded(max(lens)), padded(max(lens) + 7)
+    for i, c in enumerate(clips):
+        assert torch.equal(out[i, :lens[i]], out_longer[i, :lens[i]]), f"clip {i}: the padding leaks into the kept rows"
+        solo = gs.extract_clip_feats(torch.from_numpy(c).cuda())[0].cpu()
+        r = float((out[i, :lens[i]] - solo).norm() / solo.norm())
+        assert r < 1e-3, (i, r)
