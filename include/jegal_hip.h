@@ -157,6 +157,13 @@ int jg_jegal_gestures(jg_handle* h, const float* feats, const float* mask, int B
 /* forward_audio (jegal.py:105-113): mel (B,Tm,80) fp32 -> out (B,Ta,256) fp32, Ta = jg_audio_len(Tm). */
 int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out);
 int jg_audio_len(int Tm);
+/* forward_audio on a zero-padded batch of clips of DIFFERENT lengths with the result each clip would give alone: the reference's
+ * dataset driver runs batch_size = 1 (evaluation/extract_jegal_embs.py:141), and the conv stack's zero padding (jegal.py:41-63)
+ * makes the last audio steps of a clip depend on what follows it in a padded batch.  valid_tm_host (B) int32 on the HOST: mel
+ * frames clip b really holds (4..Tm; rows beyond must be present in `mel` but are never read as data).  Rows t < jg_audio_len(
+ * valid_tm_host[b]) of out[b] equal jg_jegal_audio on the clip alone up to fp32 summation order; rows beyond are unspecified.
+ * NULL = jg_jegal_audio. */
+int jg_jegal_audio_ragged(jg_handle* h, const float* mel, int B, int Tm, const int32_t* valid_tm_host, float* out);
 /* wav2filterbanks (utils/audio_utils.py:28-66): wav (B,n_samples) fp32 (int16 scale, NOT normalised: audio_utils.py:20-25),
  * mel_basis (80,257) fp32 = librosa.filters.mel(sr=16000,n_fft=512,n_mels=80,fmin=0,fmax=8000) -> out (B, n_samples/160, 80) log-mel. */
 int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out);

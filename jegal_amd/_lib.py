@@ -40,6 +40,7 @@ _SIGS = {
     "jg_debug_conv_rows": [_P, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)],
     "jg_jegal_gestures": [_P, _P, _P, _I, _I, _I, _P],
     "jg_jegal_audio": [_P, _P, _I, _I, _P],
+    "jg_jegal_audio_ragged": [_P, _P, _I, _I, ctypes.POINTER(ctypes.c_int32), _P],
     "jg_audio_len": [_I],
     "jg_logmel": [_P, _P, _I, _I, _P, _P],
     "jg_mask_resize": [_P, _P, _I, _I, _I, _P, _P],
@@ -300,14 +301,22 @@ class Engine:
     def audio_len(self, Tm):
         return int(self.lib.jg_audio_len(int(Tm)))
 
-    def jegal_audio(self, mel):
+    def jegal_audio(self, mel, valid_len=None):
+        """mel (B,Tm,80) -> (B, audio_len(Tm), 256).  valid_len (B ints, optional): mel frames each clip of a zero-padded batch
+        really holds -- rows t < audio_len(valid_len[b]) of clip b then equal the clip run alone (jg_jegal_audio_ragged)."""
         self._bind_stream()
         mel = self._f32(mel)
         B, Tm, F = mel.shape
         if F != 80:
             raise ValueError("mel must have 80 bands")
         out = torch.empty((B, self.audio_len(Tm), 256), dtype=torch.float32, device=self.device)
-        self._ck(self.lib.jg_jegal_audio(self.h, _ptr(mel), B, Tm, _ptr(out)))
+        if valid_len is None:
+            self._ck(self.lib.jg_jegal_audio(self.h, _ptr(mel), B, Tm, _ptr(out)))
+            return out
+        v = [int(x) for x in valid_len]
+        if len(v) != B:
+            raise ValueError("valid_len needs one entry per clip")
+        self._ck(self.lib.jg_jegal_audio_ragged(self.h, _ptr(mel), B, Tm, (ctypes.c_int32 * B)(*v), _ptr(out)))
         return out
 
     def mask_resize(self, frames_u8, mask_y):

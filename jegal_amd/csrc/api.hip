@@ -150,6 +150,7 @@ struct jg_handle {
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
     size_t feats_cap = 0;
+    std::vector<int32_t> audio_valid;   // host copy of the last jg_jegal_audio_ragged call's valid lengths (source of a stream-ordered upload)
     // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
@@ -1008,7 +1009,10 @@ int audio_len(int Tm) {
     return (h1 + 2 - 3) / 2 + 1;
 }
 
-int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) {
+// valid_host (optional, host [B]): clip b holds valid_host[b] mel frames, the rest of its Tm rows is batch padding.  Every layer's
+// rows beyond the clip's own extent are zeroed (launch_zero_tail), i.e. each clip sees the zero padding it would see alone -- the
+// reference's dataset driver runs one clip per step (extract_jegal_embs.py:141), so its result never depends on a longer neighbour.
+int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, const int32_t* valid_host, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (B <= 0 || Tm < 4) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and Tm >= 4");
     const int F = 80;
@@ -1018,6 +1022,19 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) 
     const ConvGeom g12 = geom(g9.OH, g9.OW, 256, 3, 3, 1, 3, 1, 1);
     const ConvGeom g15 = geom(g12.OH, g12.OW, 256, 1, 1, 1, 3, 0, 0);
     if (g15.OW != 1) JG_FAIL(h, JG_ERR_ARG, "audio CNN must reduce 80 mel bands to 1");
+    int* valid = nullptr;
+    if (valid_host) {
+        bool ragged = false;
+        for (int b = 0; b < B; ++b) {
+            if (valid_host[b] < 4 || valid_host[b] > Tm) JG_FAIL(h, JG_ERR_ARG, "valid_tm[%d] = %d outside 4..Tm = %d", b, valid_host[b], Tm);
+            ragged |= valid_host[b] != Tm;
+        }
+        if (ragged) {
+            h->audio_valid.assign(valid_host, valid_host + B);          // stays alive until the next call: the copy below is stream-ordered
+            RET(wsalloc(h, (size_t)B, &valid));
+            HIPCHK(h, hipMemcpyAsync(valid, h->audio_valid.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+        }
+    }
     f16 *c0, *c3, *c6, *c9, *c12, *c15;
     const long M0 = (long)B * Tm * F;
     RET(wsalloc(h, (size_t)M0 * 32, &c0));
@@ -1026,14 +1043,21 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, float* out) 
     RET(wsalloc(h, (size_t)B * g9.OH * g9.OW * 256, &c9));
     RET(wsalloc(h, (size_t)B * g12.OH * g12.OW * 256, &c12));
     RET(wsalloc(h, (size_t)B * g15.OH * 256, &c15));
+    auto tail = [&](f16* x, int halvings, const ConvGeom& g, int C) -> int {
+        if (!valid) return JG_OK;
+        return timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_zero_tail, x, (const int*)valid, halvings, B, g.OH, (long)g.OW * C, h->stream); });
+    };
     // cnn.0 + BN + ReLU straight from the mel frames (round 2: im2col + a K = 32 GEMM on the register-staged kernel)
-    RET(timed(h, JG_ST_CONV, [&] { return LAUNCH(h, launch_audio_conv0, mel, B, Tm, F, h->a0.wh, h->a0.wl, h->a0.bias, c0, h->stream); }));
+    RET(timed(h, JG_ST_CONV, [&] { return LAUNCH(h, launch_audio_conv0, mel, B, Tm, F, h->a0.wh, h->a0.wl, h->a0.bias, c0, (const int*)valid, h->stream); }));
     Epi e; e.relu = 1;
     e.out16 = c3; RET(gemm(h, JG_ST_CONV, c0, 0, B * g3.OH * g3.OW, h->a3, e, &g3));
+    RET(tail(c3, 1, g3, 64));
     e.out16 = c6; RET(gemm(h, JG_ST_CONV, c3, 0, B * g6.OH * g6.OW, h->a6, e, &g6));
+    RET(tail(c6, 2, g6, 128));
     e.out16 = c9; RET(gemm(h, JG_ST_CONV, c6, 0, B * g9.OH * g9.OW, h->a9, e, &g9));
+    RET(tail(c9, 2, g9, 256));
     e.out16 = c12; RET(gemm(h, JG_ST_CONV, c9, 0, B * g12.OH * g12.OW, h->a12, e, &g12));
-    e.relu = 0;
+    e.relu = 0;      // (cnn.15 is 1x1: rows of c12 beyond a clip's extent only reach output rows beyond it, which callers strip)
     e.out16 = c15; RET(gemm(h, JG_ST_CONV, c12, 0, B * g15.OH, h->a15, e, &g15));
     Epi o; o.out32 = out;
     return gemm(h, JG_ST_GEMM, c15, 256, B * g15.OH, h->op_audio, o);
@@ -1484,7 +1508,14 @@ int jg_jegal_audio(jg_handle* h, const float* mel, int B, int Tm, float* out) {
     ENTER(h);
     if (!mel || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     h->ws.reset();
-    return jegal_audio_impl(h, mel, B, Tm, out);
+    return jegal_audio_impl(h, mel, B, Tm, nullptr, out);
+}
+
+int jg_jegal_audio_ragged(jg_handle* h, const float* mel, int B, int Tm, const int32_t* valid_tm_host, float* out) {
+    ENTER(h);
+    if (!mel || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    h->ws.reset();
+    return jegal_audio_impl(h, mel, B, Tm, valid_tm_host, out);
 }
 
 int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const int32_t* mask_y, uint8_t* dst) {

@@ -231,7 +231,11 @@ hipError_t launch_cast_f32_f16(const float* in, f16* out, long n, hipStream_t s)
 hipError_t launch_transpose_tokens(const float* in, int N, int L, int D, float* out, hipStream_t s);
 hipError_t launch_l2norm(const float* in, float* out, int rows, int D, hipStream_t s);
 // first audio conv (5x5, 1 -> 32 channels, BN folded, ReLU) straight from the mel frames: wh / wl = the packed [32][32] weights (k = tap)
-hipError_t launch_audio_conv0(const float* mel, int B, int Tm, int F, const f16* wh, const f16* wl, const float* bias, f16* out, hipStream_t s);
+// valid (optional, device [B]): per-clip number of valid mel frames in a zero-padded batch (see zero_tail_kernel, elementwise.hip)
+hipError_t launch_audio_conv0(const float* mel, int B, int Tm, int F, const f16* wh, const f16* wl, const float* bias, f16* out, const int* valid,
+                              hipStream_t s);
+// NHWC [B][H][..row_elems..] fp16: rows h >= len_b of clip b set to zero, len_b = valid[b] halved (len-1)/2+1 `halvings` times
+hipError_t launch_zero_tail(f16* x, const int* valid, int halvings, int B, int H, long row_elems, hipStream_t s);
 hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int n, f16* dst16, float* dst32,
                                int dst_ld, int dst_col, hipStream_t s);
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);

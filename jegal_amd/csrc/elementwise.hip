@@ -359,8 +359,11 @@ hipError_t launch_l2norm(const float* in, float* out, int rows, int D, hipStream
 // rounded to the 16-bit operand type, fp32 accumulation; only the summation order differs).  One thread per output pixel: the
 // 5 x 5 neighbourhood comes from a mel tile in LDS, the 25 x 32 weights are wave-uniform (fp32 copy in LDS, broadcast reads),
 // 800 FMAs per pixel, one 64-byte NHWC store.  W2 modes carry the lo part of the weights in the same fp32 copy.
+// valid (optional, [B]): clip b holds only valid[b] mel frames -- frames beyond are read as the zero padding the clip would see alone,
+// and output rows beyond are written as zeros (the next layer's zero padding): see zero_tail_kernel.
 __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restrict__ mel, int B, int Tm, int F, const f16* __restrict__ wh,
-                                                          const f16* __restrict__ wl, const float* __restrict__ bias, f16* __restrict__ out) {
+                                                          const f16* __restrict__ wl, const float* __restrict__ bias, f16* __restrict__ out,
+                                                          const int* __restrict__ valid) {
     constexpr int TR = 3, FW_MAX = 84;                   // 3 output rows x F (<= 80) per block: (TR + 4) x (F + 4) mel values staged
     __shared__ float sm[(TR + 4) * FW_MAX];
     __shared__ float sw[25 * 32];
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int tiles_t = (Tm + TR - 1) / TR;
     const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x - b * tiles_t) * TR;
+    const int Tv = valid ? min(max(valid[b], 0), Tm) : Tm;
     for (int i = tid; i < 25 * 32; i += 256) {
         const int tap = i >> 5, oc = i & 31;
         sw[i] = (float)wh[oc * 32 + tap] + (wl ? (float)wl[oc * 32 + tap] : 0.f);
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restric
         const int r = i / FW, c = i - r * FW;
         const int tt = t0 + r - 2, ff = c - 2;
         float x = 0.f;
-        if (tt >= 0 && tt < Tm && ff >= 0 && ff < F) x = mel[((long)b * Tm + tt) * F + ff];
+        if (tt >= 0 && tt < Tv && ff >= 0 && ff < F) x = mel[((long)b * Tm + tt) * F + ff];
         sm[r * FW_MAX + c] = (float)(f16)x;             // the operand rounding of the GEMM path
     }
     __syncthreads();
@@ -397,17 +401,41 @@ __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restric
             for (int oc = 0; oc < 32; ++oc) acc[oc] = __builtin_fmaf(x, w[oc], acc[oc]);
         }
     f16 o[32];
+    const bool live = t0 + r < Tv;
 #pragma unroll
-    for (int oc = 0; oc < 32; ++oc) o[oc] = (f16)fmaxf(acc[oc] + sb[oc], 0.f);
+    for (int oc = 0; oc < 32; ++oc) o[oc] = live ? (f16)fmaxf(acc[oc] + sb[oc], 0.f) : (f16)0.f;
     uint4* d = reinterpret_cast<uint4*>(out + (((long)b * Tm + t0 + r) * F + f) * 32);
 #pragma unroll
     for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<uint4*>(&o[q * 8]);
 }
 
-hipError_t launch_audio_conv0(const float* mel, int B, int Tm, int F, const f16* wh, const f16* wl, const float* bias, f16* out, hipStream_t s) {
+hipError_t launch_audio_conv0(const float* mel, int B, int Tm, int F, const f16* wh, const f16* wl, const float* bias, f16* out, const int* valid,
+                              hipStream_t s) {
     if (B <= 0 || Tm <= 0) return hipSuccess;
     if (F < 1 || F > 80 || 3 * F > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(audio_conv0_kernel, dim3((unsigned)(B * ((Tm + 2) / 3))), dim3(256), 0, s, mel, B, Tm, F, wh, wl, bias, out);
+    hipLaunchKernelGGL(audio_conv0_kernel, dim3((unsigned)(B * ((Tm + 2) / 3))), dim3(256), 0, s, mel, B, Tm, F, wh, wl, bias, out, valid);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-clip valid lengths in a zero-padded audio batch (evaluation/extract_jegal_embs.py:141 runs batch_size = 1: a clip never
+// sees another clip's length).  Layer outputs are NHWC [b][h][w][c] with h = time; a clip of valid[b] mel frames has
+// len = valid[b] rows after the stride-1 layers and (len - 1) / 2 + 1 after each stride-2 layer (3x3, pad 1).  Rows h >= len of
+// clip b are set to zero, which is exactly the zero padding the next conv layer would apply to the clip alone -- the rows
+// h < len of every layer then do not depend on the batch's longest clip.  One block per (b, h) row.
+__global__ __launch_bounds__(256) void zero_tail_kernel(f16* __restrict__ x, const int* __restrict__ valid, int halvings, int H, int row_vec) {
+    const int b = blockIdx.x / H, hrow = blockIdx.x - b * H;
+    int len = max(valid[b], 0);
+    for (int i = 0; i < halvings; ++i) len = len > 0 ? (len - 1) / 2 + 1 : 0;
+    if (hrow < len) return;
+    uint4* p = reinterpret_cast<uint4*>(x) + (long)blockIdx.x * row_vec;
+    for (int i = threadIdx.x; i < row_vec; i += 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+hipError_t launch_zero_tail(f16* x, const int* valid, int halvings, int B, int H, long row_elems, hipStream_t s) {
+    if (B <= 0 || H <= 0 || !valid) return hipSuccess;
+    if (row_elems % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, x, valid, halvings, H, (int)(row_elems / 8));
     return hipGetLastError();
 }
 
