@@ -322,13 +322,17 @@ def main():
         for _ in range(n):
             eng.extract_gesture(src, out)
         sync_all()
-        tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        mine = time.perf_counter() - t0
+        tmax = torch.tensor([mine], dtype=torch.float64, device=dev)
         jdist.all_reduce_max(tmax)
+        per_rank, _ = jdist.all_gather_rows(torch.tensor([[mine]], dtype=torch.float64, device=dev))      # a straggler shows up here
+        timed_loop.per_rank_s = [float(v) for v in per_rank.flatten().cpu()]
         return float(tmax.item())
 
     for _ in range(args.warmup):
         eng.extract_gesture(frames, out)
     dt = timed_loop(args.steps)
+    per_rank_ms = [v / args.steps * 1e3 for v in timed_loop.per_rank_s]
     assert torch.isfinite(out).all(), "non-finite embeddings"
 
     # ---- per-kernel timing with HIP events on the launch stream (dominant kernel: conv1)
@@ -411,6 +415,26 @@ def main():
         tm = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         jdist.all_reduce_max(tm)
         extras["retrieval"] = {"n": N, "ms": float(tm.item()) * 1e3, "metrics": m_sharded}
+        # config 5: spotting over 4 000 clips (W = 30), clips sharded ceil(N/G) per rank, two counters all-reduced
+        NS = 4000
+        sg, sc, sb, stg = synth.planted_spotting(1238, NS)
+        lo5, hi5 = jdist.shard_range(NS)
+        M.spotting_accuracy(sg[lo5:hi5], sc[lo5:hi5], sb[lo5:hi5], stg[lo5:hi5], engine=eng)       # warm-up
+        sync_all()
+        t0 = time.perf_counter()
+        acc5 = M.spotting_accuracy(sg[lo5:hi5], sc[lo5:hi5], sb[lo5:hi5], stg[lo5:hi5], engine=eng)
+        sync_all()
+        tm5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        jdist.all_reduce_max(tm5)
+        extras["spotting"] = {"n": NS, "words": 30, "ms": float(tm5.item()) * 1e3, "accuracy": acc5,
+                              "what": "BASELINE configs[4]: seed-1238 planted clips, clips sharded over the ranks, (correct, total) all-reduced; "
+                                      "ms includes the host-side concatenation and upload of the rank's block"}
+        if rank == 0:
+            p5, s5 = eng.spot(torch.from_numpy(np.concatenate(sg)), torch.from_numpy(np.concatenate(sc)), M._offsets(sg), M._offsets(sc), stg)
+            c5, n5 = M.spotting_counts(p5.cpu().numpy(), s5.cpu().numpy(), sb, stg)
+            assert acc5 == 100.0 * c5 / n5, ("sharded spotting accuracy differs from the single-rank result", acc5, c5, n5)
+            extras["spotting"]["equals_single_rank"] = True
+        del sg, sc
         if rank == 0:
             r_all, t_all = eng.sim_rank(eng.l2norm(torch.from_numpy(ce).to(dev)), eng.l2norm(torch.from_numpy(ge).to(dev)))
             m_single = M.metrics_from_ranks(r_all.cpu().numpy(), t_all.cpu().numpy())
@@ -474,6 +498,7 @@ def main():
         res = {
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == 4 else "f16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic batch=32 gesture-only (GestSync conv + JEGAL gesture encoder), "
@@ -535,6 +560,7 @@ def main():
                                         "value": args.clips * world * args.steps / extras["single_stream_s"], "unit": "clips/s",
                                         "what": "the same timed loop with dual_stream=0 (every batch on one stream); stage_ms_per_step and the roofline objects are measured in this mode"}
             res["retrieval_config4"] = extras["retrieval"]
+            res["spotting_config5"] = extras["spotting"]
             if "config3" in extras:
                 res["config3"] = extras["config3"]
             if "pcie_clips_per_s" in extras:

@@ -122,8 +122,9 @@ class Engine:
         if rc != 0:
             raise JegalError(f"jg_create({device_index}) failed with {rc}")
         self.h = h
+        self.precision = PREC_FP16_BC              # the library's default (jg_handle::precision)
         if precision is not None:
-            self._ck(self.lib.jg_set_precision(self.h, precision))
+            self.set_precision(precision)
         self.finalized = 0
 
     def close(self):
@@ -144,6 +145,7 @@ class Engine:
     # ---- weights
     def set_precision(self, mode):
         self._ck(self.lib.jg_set_precision(self.h, mode))
+        self.precision = int(mode)
 
     def set_option(self, name, value):
         self._ck(self.lib.jg_set_option(self.h, name.encode(), int(value)))

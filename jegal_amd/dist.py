@@ -42,6 +42,9 @@ def _backend():
     return td.get_backend() if td.is_available() and td.is_initialized() else None
 
 
+backend = _backend
+
+
 def all_gather_rows(x):
     """Gather ragged row blocks (n_r, D) from every rank in rank order.
     Returns (full (sum n_r, D), row offset of this rank's block).

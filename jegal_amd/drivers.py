@@ -46,15 +46,17 @@ def _add_precision_args(p):
                    help=".npy of masked uint8 crops (B,T,270,480,3) or (T,270,480,3): re-run the precision-mode-3 calibration on them")
 
 
-def pick_precision(args, checkpoints):
+def pick_precision(args, checkpoints, can_calibrate=True):
     """The default precision mode folds (w - fp16(w)).E[x] into every Linear bias, with E[x] recorded on built-in synthetic clips.
     That calibration was only ever validated on the synthetic weights (no checkpoints ship with the reference), so a REAL
-    checkpoint gets the calibration-free hi+lo mode unless the caller supplies calibration clips."""
+    checkpoint gets the calibration-free hi+lo mode unless the caller supplies calibration clips AND
+    the command can run the calibration on them (can_calibrate: it needs the GestSync model, frames -> features -> JEGAL)."""
     from ._lib import PREC_FP16_BC, PREC_FP16_W2
     if getattr(args, "precision", None) is not None:
         return args.precision
     real = any(c is not None and c != "synthetic" for c in checkpoints)
-    return PREC_FP16_W2 if real and not getattr(args, "calibrate_frames", None) else PREC_FP16_BC
+    calibrated = bool(getattr(args, "calibrate_frames", None)) and can_calibrate
+    return PREC_FP16_W2 if real and not calibrated else PREC_FP16_BC
 
 
 def _models(args, need_gestsync=False, need_jegal=False):
@@ -66,9 +68,14 @@ def _models(args, need_gestsync=False, need_jegal=False):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     eng = Engine.get()
     prec = pick_precision(args, [getattr(args, "checkpoint_path_gestsync", None) if need_gestsync else None,
-                                 getattr(args, "checkpoint_path", None) if need_jegal else None])
+                                 getattr(args, "checkpoint_path", None) if need_jegal else None], can_calibrate=need_gestsync)
+    if getattr(args, "calibrate_frames", None) and not need_gestsync:
+        print("Note: --calibrate_frames needs the GestSync model and is ignored by this command (precision mode {})".format(prec))
     if eng.finalized == 0:
         eng.set_precision(prec)
+    elif (need_gestsync or need_jegal) and eng.precision != prec:
+        raise RuntimeError("this process already holds an engine finalized in precision mode {}; mode {} was asked for "
+                           "(close the engine or start a new process)".format(eng.precision, prec))
     gs = jg = None
     if need_gestsync:
         gs = GestSync(engine=eng).load_state_dict(load_checkpoint(args.checkpoint_path_gestsync, "gestsync"))
@@ -88,6 +95,7 @@ def cmd_extract_gestsync_feats(argv):
     p.add_argument("--result_dir", required=True)
     p.add_argument("--batch_size", type=int, default=48, help="accepted for compatibility; windows are never materialised")
     p.add_argument("--clips_per_batch", type=int, default=16, help="clips of similar length processed per engine call (padded to the longest with its last frame: exact)")
+    p.add_argument("--frames_per_batch", type=int, default=4800, help="upper bound on clips x longest clip per engine call (workspace / host memory bound)")
     p.add_argument("--rank", type=int, default=None)
     p.add_argument("--nshard", type=int, default=None)
     _add_precision_args(p)
@@ -107,38 +115,71 @@ def cmd_extract_gestsync_feats(argv):
     # Clips of different lengths go through the engine in batches: a clip padded with copies of its LAST frame gives, for its own
     # T frames, exactly the windows of the reference's edge padding (inference_embs.py:283 replicates the last frame 12 times;
     # window t only reaches frame t+12) - so a batch is padded to its longest clip, the first T_i rows of clip i are kept, and
-    # the GEMMs see clips_per_batch clips at once instead of one.  Files are sorted by length to keep the padding small.
+    # the GEMMs see several clips at once instead of one.  Files are sorted by length to keep the padding small.  A batch is
+    # bounded by clips AND by padded frames (--frames_per_batch): the engine's workspace grows with clips x Tmax (about 2.9 MB per
+    # conv position) and the host array with 388 KB per frame, so long tracks go through in small groups or alone, as the
+    # reference's one-video-at-a-time loop bounds them (extract_gestsync_feats.py:314-344).
     def clip_len(f):
         try:
-            shp = np.load(f, mmap_mode="r").shape
-            return shp[0] if len(shp) == 4 and tuple(shp[1:]) == (270, 480, 3) else -1
+            m = np.load(f, mmap_mode="r")
+            if m.dtype != np.uint8:
+                return -2
+            return m.shape[0] if m.ndim == 4 and tuple(m.shape[1:]) == (270, 480, 3) and m.shape[0] > 0 else -1
         except Exception:
             return -1
     sized = sorted(((clip_len(f), f, out) for f, out in todo), key=lambda x: x[0])
     for T_bad, f, _ in [x for x in sized if x[0] <= 0]:
         err += 1
-        print("Error: ", "expected a (T,270,480,3) uint8 .npy", " | Video file: ", f)
+        print("Error: ", "expected uint8 crops" if T_bad == -2 else "expected a (T,270,480,3) uint8 .npy", " | Video file: ", f)
     sized = [x for x in sized if x[0] > 0]
-    nb = max(1, args.clips_per_batch)
-    for s0 in range(0, len(sized), nb):
-        group = sized[s0:s0 + nb]
+
+    def run_group(group):
+        """Features of a group of clips (padded to its longest); returns the list of (T,1024) arrays."""
+        Tmax = max(t for t, _, _ in group)
+        batch = np.empty((len(group), Tmax, 270, 480, 3), np.uint8)
+        for i, (t, f, _) in enumerate(group):
+            fr = np.load(f)
+            batch[i, :t] = fr
+            batch[i, t:] = fr[t - 1]
+        feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device)).cpu().numpy()
+        return [feats[i, :t] for i, (t, _, _) in enumerate(group)]
+
+    def save_one(feat, out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        np.save(out, feat)
+
+    nb, fmax = max(1, args.clips_per_batch), max(1, args.frames_per_batch)
+    s0 = 0
+    while s0 < len(sized):
+        s1 = s0 + 1                                   # sorted by length: the last clip of a group is its longest
+        while s1 < len(sized) and s1 - s0 < nb and (s1 - s0 + 1) * sized[s1][0] <= fmax:
+            s1 += 1
+        group = sized[s0:s1]
+        s0 = s1
         try:
-            Tmax = max(t for t, _, _ in group)
-            batch = np.empty((len(group), Tmax, 270, 480, 3), np.uint8)
-            for i, (t, f, _) in enumerate(group):
-                fr = np.load(f)
-                if fr.dtype != np.uint8:
-                    raise ValueError("expected uint8 crops, got %s in %s" % (fr.dtype, f))
-                batch[i, :t] = fr
-                batch[i, t:] = fr[t - 1]
-            feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device)).cpu().numpy()
-            for i, (t, f, out) in enumerate(group):
-                os.makedirs(os.path.dirname(out), exist_ok=True)
-                np.save(out, feats[i, :t])
+            feats = run_group(group)
+        except Exception as e:                       # one bad file must not take its neighbours down: retry the group clip by clip
+            if len(group) == 1:
+                err += 1
+                print("Error: ", e, " | Video file: ", group[0][1])
+                continue
+            feats = []
+            for item in group:
+                try:
+                    feats.append(run_group([item])[0])
+                except Exception as e1:              # per-file try/except as in the reference (:347-351)
+                    feats.append(None)
+                    err += 1
+                    print("Error: ", e1, " | Video file: ", item[1])
+        for feat, (t, f, out) in zip(feats, group):
+            if feat is None:
+                continue
+            try:
+                save_one(feat, out)
                 saved += 1
-        except Exception as e:                       # per-batch try/except (the reference: per file, :347-351)
-            err += len(group)
-            print("Error: ", e, " | Video files: ", [f for _, f, _ in group])
+            except Exception as e:
+                err += 1
+                print("Error: ", e, " | Video file: ", f)
     print("No of files saved = {} | Err = {}".format(saved, err))
     return 0
 
@@ -159,7 +200,7 @@ def cmd_extract_jegal_embs(argv):
     p.add_argument("--feature_dir", required=True)
     p.add_argument("--text_states_dir", default=None)
     p.add_argument("--modalities", default="vta", choices=["vta", "vt", "va", "ta", "v", "t", "a"])
-    p.add_argument("--batch_size", type=int, default=16)
+    p.add_argument("--batch_size", type=int, default=16, help="clips per engine call (the reference: 1; results are those of batch size 1 whatever this is)")
     _add_precision_args(p)
     args = p.parse_args(argv)
     eng, _, jg = _models(args, need_jegal=True)
@@ -225,8 +266,17 @@ def cmd_extract_jegal_embs(argv):
                 st[i, :l], tm[i, :l], ids[i, :l], offs[i, :l] = it["text"]
             tbatch = [str(it["row"].phrase).split(" ") for it in batch]
             text = (torch.from_numpy(st), torch.from_numpy(tm), tbatch, ids, offs)
-        am = None if audio is None else torch.ones((n, eng.audio_len(audio.shape[1])))
-        out = jg.forward_inference(visual_feats=vis, visual_mask=mask, text=text, audio=audio, audio_mask=am, word_boundaries=wbs)
+        am = alens = None
+        if audio is not None:
+            alens = [it["mel"].shape[0] for it in batch]
+            am = torch.zeros((n, eng.audio_len(audio.shape[1])))
+            for i, l in enumerate(alens):
+                am[i, :l // 4] = 1                    # dataset.py:291 (unused by the model, kept for the signature)
+        # per_clip=True: the reference runs this script with batch_size=1 (extract_jegal_embs.py:141), so a clip's result must not
+        # depend on the clips it happens to be batched with here -- the last word's text range ends at the clip's own token
+        # count and the audio conv stack sees every clip's own zero padding (jegal_amd/jegal.py, jg_jegal_audio_ragged)
+        out = jg.forward_inference(visual_feats=vis, visual_mask=mask, text=text, audio=audio, audio_mask=am, word_boundaries=wbs,
+                                   audio_lens=alens, per_clip=True)
         gesture = content = None
         if vis is not None and (text is not None or audio is not None):
             gesture, content = out
@@ -320,7 +370,8 @@ def cmd_evaluate_asd(argv):
             return pickle.load(f)
 
     queries, cands = [], []
-    for i in range(len(df)):
+    lo, hi = jdist.shard_range(len(df))           # queries sharded over the ranks (contiguous blocks), counters all-reduced
+    for i in range(lo, hi):
         row = df.iloc[i]
         q = load(row.filename)
         if q is None:
@@ -332,10 +383,12 @@ def cmd_evaluate_asd(argv):
                 cs.append(np.asarray(d["gesture_emb"], np.float32).mean(axis=0))
         queries.append(np.asarray(q["content_emb"], np.float32).mean(axis=0))
         cands.append(np.stack(cs))
-    a2, a4, a6 = M.asd_accuracy(np.stack(queries), cands, engine=eng)
-    print("Total videos evaluated: {}".format(len(queries)))
-    for k, a in ((2, a2), (4, a4), (6, a6)):
-        print("{} spk: Acc: {:.3f}".format(k, a))
+    a2, a4, a6 = M.asd_accuracy(np.stack(queries) if queries else np.zeros((0, 512), np.float32), cands, engine=eng)
+    total = M.reduce_counts([len(queries)], eng.device)[0]
+    if jdist.rank() == 0:
+        print("Total videos evaluated: {}".format(total))
+        for k, a in ((2, a2), (4, a4), (6, a6)):
+            print("{} spk: Acc: {:.3f}".format(k, a))
     return a2, a4, a6
 
 

@@ -17,21 +17,29 @@ from ._lib import Engine
 SPECIAL_IDS = (0, 2, 1)      # xlm-roberta <s>, </s>, <pad>  (jegal.py:136)
 
 
-def text_word_segments(input_ids, offset_mapping, text_batch):
+def text_word_segments(input_ids, offset_mapping, text_batch, lengths=None):
     """Row ranges of get_word_level_embs (jegal.py:141-205).  Returns (per-sample list of
-    (start,end_excl) or None for dropped samples, invalid indices)."""
+    (start,end_excl) or None for dropped samples, invalid indices).
+
+    The reference ends the LAST word's range at ``input_ids.shape[1]`` (jegal.py:168-171), i.e. at the padded length of the
+    batch: it swallows ``</s>`` and, in a batch with a longer sentence, the pad rows too.  ``lengths`` (one token count per
+    sample, e.g. ``attention_mask.sum(1)``) ends it at the sample's OWN length instead -- what the reference computes when the
+    sample is alone in its batch, which is how its dataset driver runs (evaluation/extract_jegal_embs.py:141, batch_size=1)."""
     ids = np.asarray(input_ids.cpu() if isinstance(input_ids, torch.Tensor) else input_ids)
     offs = np.asarray(offset_mapping.cpu() if isinstance(offset_mapping, torch.Tensor) else offset_mapping)
     L = ids.shape[1]
     segs, invalid = [], []
     for b in range(ids.shape[0]):
-        starts = [i for i in range(L) if offs[b, i, 0] == 0 and int(ids[b, i]) not in SPECIAL_IDS]
+        Lb = L if lengths is None else int(lengths[b])
+        if not 0 < Lb <= L:
+            raise ValueError(f"text length {Lb} of sample {b} outside 1..{L}")
+        starts = [i for i in range(Lb) if offs[b, i, 0] == 0 and int(ids[b, i]) not in SPECIAL_IDS]
         cur, ok = [], True
         for idx, _word in enumerate(text_batch[b]):
             if idx >= len(starts):
                 ok = False
                 break
-            end = starts[idx + 1] if idx < len(starts) - 1 else L
+            end = starts[idx + 1] if idx < len(starts) - 1 else Lb
             cur.append((starts[idx], end))
         if not ok or len(cur) == 0:
             invalid.append(b)
@@ -43,9 +51,14 @@ def text_word_segments(input_ids, offset_mapping, text_batch):
 
 def audio_word_segments(word_boundaries, n_frames, invalid=None):
     """Row ranges of get_audio_word_level_embs (jegal.py:218-245): python slice semantics of
-    audio_emb[b, s-s0 : e-s0+1]; an empty slice is an IndexError as in the reference (:239)."""
+    audio_emb[b, s-s0 : e-s0+1]; an empty slice is an IndexError as in the reference (:239).
+    n_frames: audio steps of the batch, or one count per sample (the sample's own steps: the slice of a clip alone in its
+    batch is clipped to ITS length, not to a longer neighbour's)."""
     segs = []
+    per_sample = None if np.isscalar(n_frames) else [int(n) for n in n_frames]
     for b, wbs in enumerate(word_boundaries):
+        if per_sample is not None:
+            n_frames = per_sample[b]
         if invalid is not None and b in invalid:
             segs.append(None)
             continue
@@ -153,9 +166,19 @@ class JEGAL:
 
     # ---- the inference entry point (jegal.py:377-420)
     def forward_inference(self, visual_feats=None, visual_mask=None, text=None, audio=None, audio_mask=None,
-                          word_boundaries=None):
+                          word_boundaries=None, audio_lens=None, per_clip=False):
+        """jegal.py:377-420.  Default: the reference's semantics for the batch as given -- including its dependence on the
+        batch's padded lengths (the last word's text range runs to the padded L, jegal.py:168-171; the audio conv stack sees a
+        shorter clip's zero padding as data, jegal.py:41-63).
+
+        per_clip=True (not in the reference's signature): every clip of a padded batch gets the result it would get ALONE in
+        its batch, which is how the reference's dataset driver runs (evaluation/extract_jegal_embs.py:141, batch_size=1):
+        text lengths from ``text_mask.sum(1)``, audio lengths from ``audio_lens`` (mel frames per clip, required with audio),
+        gesture rows are batch-independent already (key mask).  Rows beyond a clip's own T / W stay for the caller to strip."""
         self._check()
         eng = self.engine
+        if per_clip and audio is not None and audio_lens is None:
+            raise ValueError("per_clip=True needs audio_lens (mel frames of every clip) when audio is given")
         gesture = None
         if visual_feats is not None:
             gesture = eng.jegal_gestures(visual_feats, visual_mask, align=True)
@@ -167,13 +190,17 @@ class JEGAL:
             pack = text if isinstance(text, tuple) else self.get_roberta_embeddings(text)
             text_feats, text_mask, text_batch, input_ids, offset_mapping = pack
             sub = eng.jegal_text(text_feats, text_mask)
-            t_segs, _invalid = text_word_segments(input_ids, offset_mapping, text_batch)
+            t_len = None
+            if per_clip:
+                tm = text_mask.cpu().numpy() if isinstance(text_mask, torch.Tensor) else np.asarray(text_mask)
+                t_len = (tm.reshape(len(text_batch), -1) != 0).sum(1)
+            t_segs, _invalid = text_word_segments(input_ids, offset_mapping, text_batch, t_len)
             t_rows = [b for b in range(len(t_segs)) if t_segs[b] is not None]
             if not t_rows:
                 raise ValueError("max() arg is an empty sequence")       # pad_wordlevel_embs on an empty list
         if audio is not None:
-            frames = eng.jegal_audio(audio)
-            a_segs = audio_word_segments(word_boundaries, frames.shape[1])
+            frames = eng.jegal_audio(audio, audio_lens if per_clip else None)
+            a_segs = audio_word_segments(word_boundaries, [eng.audio_len(n) for n in audio_lens] if per_clip else frames.shape[1])
             a_rows = list(range(len(a_segs)))
         rows = t_rows if t_rows is not None else a_rows
         Wt = max(len(t_segs[b]) for b in t_rows) if t_rows is not None else None

@@ -61,9 +61,33 @@ def retrieval_metrics(emb1, emb2, engine=None):
     return metrics_from_ranks(rank.flatten().cpu().numpy(), ties.flatten().cpu().numpy())
 
 
+def reduce_counts(counts, device=None):
+    """Sum a short list of integer counters over the ranks (spotting / ASD need only this): every rank evaluates ITS
+    contiguous block of clips (jdist.shard_range) and the totals are all-reduced -- RCCL on device tensors under nccl, host
+    tensors under gloo.  Single process: the counts themselves."""
+    counts = [int(c) for c in counts]
+    if jdist.world_size() == 1:
+        return counts
+    t = torch.tensor(counts, dtype=torch.int64, device=device if jdist.backend() == "nccl" else "cpu")
+    return [int(v) for v in jdist.all_reduce_sum(t).cpu()]
+
+
+def spotting_counts(pred, score, word_boundaries, target_idx, thresh=0.5, frame_thresh=9):
+    """(correct, total) of get_spotting_acc (evaluate_spotting.py:59-90) from the per-clip argmax frame and its probability:
+    correct iff start - frame_thresh <= pred <= end + frame_thresh and score >= thresh (:77-84)."""
+    correct = 0
+    for i, (wb, t) in enumerate(zip(word_boundaries, target_idx)):
+        s = max(0, wb[t][1] - frame_thresh)
+        e = wb[t][2] + frame_thresh
+        if s <= int(pred[i]) <= e and float(score[i]) >= thresh:
+            correct += 1
+    return correct, len(word_boundaries)
+
+
 def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, frame_thresh=9, engine=None):
     """get_spotting_acc (evaluate_spotting.py:59-90).  ``targets`` are word indices (the reference
-    looks the target boundary up in the clip's list, :70) or [word,start,end] boundaries."""
+    looks the target boundary up in the clip's list, :70) or [word,start,end] boundaries.
+    Sharded when torch.distributed is initialised: every rank passes ITS block of clips, the two counters are all-reduced."""
     eng = engine or Engine.get()
     wbs = [ast.literal_eval(w) if isinstance(w, str) else w for w in word_boundaries]
     tidx = []
@@ -71,28 +95,31 @@ def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, 
         if isinstance(t, str):
             t = ast.literal_eval(t)
         tidx.append(wb.index(t) if isinstance(t, (list, tuple)) else int(t))
-    g = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in gestures], 0))
-    c = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in contents], 0))
-    pred, score = eng.spot(g, c, _offsets(gestures), _offsets(contents), tidx)
-    pred, score = pred.cpu().numpy(), score.cpu().numpy()
     correct = 0
-    for i, (wb, t) in enumerate(zip(wbs, tidx)):
-        s = max(0, wb[t][1] - frame_thresh)
-        e = wb[t][2] + frame_thresh
-        if s <= pred[i] <= e and score[i] >= thresh:
-            correct += 1
-    total = len(wbs)
-    if jdist.world_size() > 1:
-        tot = jdist.all_reduce_sum(torch.tensor([correct, total], dtype=torch.int64, device=eng.device))
-        correct, total = int(tot[0]), int(tot[1])
+    if len(wbs):                                  # (a rank may hold no clip when there are fewer clips than ranks)
+        g = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in gestures], 0))
+        c = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in contents], 0))
+        pred, score = eng.spot(g, c, _offsets(gestures), _offsets(contents), tidx)
+        correct, _ = spotting_counts(pred.cpu().numpy(), score.cpu().numpy(), wbs, tidx, thresh, frame_thresh)
+    correct, total = reduce_counts([correct, len(wbs)], eng.device)
     return 100.0 * correct / total
+
+
+def asd_counts(pred):
+    """[correct for 2, 4, 6 speakers, queries] from jg_asd's (n,3) argmax indices: the positive is candidate 0 (evaluate_asd.py:101-113)."""
+    pred = np.asarray(pred).reshape(-1, 3)
+    return [int(np.sum(pred[:, k] == 0)) for k in range(3)] + [int(pred.shape[0])]
 
 
 def asd_accuracy(query_content, candidate_gestures, engine=None):
     """evaluate_asd.py:94-113: query_content (N,512) video-level; candidate_gestures = list of (P_i,512)
-    with the positive at index 0.  Returns accuracies for 2/4/6 speakers."""
+    with the positive at index 0.  Returns accuracies for 2/4/6 speakers.
+    Sharded when torch.distributed is initialised: every rank passes ITS block of queries, the four counters are all-reduced."""
     eng = engine or Engine.get()
-    cand = torch.cat([_tensor(c).to(eng.device) for c in candidate_gestures], 0)
-    pred = eng.asd(_tensor(query_content), cand, _offsets(candidate_gestures)).cpu().numpy()
-    n = max(1, pred.shape[0])
-    return tuple(float(np.sum(pred[:, k] == 0)) / n for k in range(3))
+    counts = [0, 0, 0, 0]
+    if len(candidate_gestures):
+        cand = torch.cat([_tensor(c).to(eng.device) for c in candidate_gestures], 0)
+        counts = asd_counts(eng.asd(_tensor(query_content), cand, _offsets(candidate_gestures)).cpu().numpy())
+    c2, c4, c6, n = reduce_counts(counts, eng.device)
+    n = max(1, n)
+    return c2 / n, c4 / n, c6 / n

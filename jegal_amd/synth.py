@@ -195,6 +195,58 @@ def synth_frames(seed, n_clips, n_frames, height=270, width=480, mask_rows=110, 
     return out
 
 
+def synth_frames_structured(seed, n_clips, n_frames, kind, height=270, width=480, mask_rows=110):
+    """Clips that are NOT uniform noise (VERDICT r3 item 2: the reference's inputs are natural crops, inference_embs.py:235-286;
+    every oracle comparison of rounds 1-3 used synth_frames).  uint8 (B,T,H,W,3), seeded, three families:
+
+    "smooth"     low-contrast smooth content: two slow sinusoidal gradients per channel plus three Gaussian blobs that drift a
+                 few pixels per frame (a torso / arms stand-in), values ~ 60..190, +-2 of pixel noise; rows [0, mask_rows) zero
+    "saturated"  hard-edged blocks of 0 / 255 per channel (cells of 24 x 32 pixels, the pattern shifts by 3 pixels per frame) --
+                 the largest conv1 sums the u8 path can see; rows [0, mask_rows) zero
+    "jitter"     the smooth content with the mask height drawn PER FRAME from 80..140, frame 3 of every clip NOT masked at all
+                 and frame 5 masked completely (inference_embs.py:264-270 blanks rows 0..y2+15 per frame; no face = no mask)
+    """
+    rng = np.random.default_rng([seed, 0x57A7])
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    out = np.empty((n_clips, n_frames, height, width, 3), np.uint8)
+    for b in range(n_clips):
+        if kind in ("smooth", "jitter"):
+            ph = rng.uniform(0, 2 * np.pi, (3, 2))
+            fx, fy = rng.uniform(0.6, 2.2, 3), rng.uniform(0.6, 2.2, 3)
+            blob = rng.uniform([60, 120, 25, 18], [420, 250, 70, 45], (3, 4))          # x0, y0, sx, sy
+            vel = rng.uniform(-2.5, 2.5, (3, 2))
+            amp = rng.uniform(25, 45, 3)
+            for t in range(n_frames):
+                img = np.empty((height, width, 3), np.float32)
+                bl = np.zeros((height, width), np.float32)
+                for k in range(3):
+                    cx, cy = blob[k, 0] + vel[k, 0] * t, blob[k, 1] + vel[k, 1] * t
+                    bl += amp[k] * np.exp(-0.5 * (((xx - cx) / blob[k, 2]) ** 2 + ((yy - cy) / blob[k, 3]) ** 2))
+                for c in range(3):
+                    img[..., c] = (118.0 + 8.0 * c + 22.0 * np.sin(2 * np.pi * fx[c] * xx / width + ph[c, 0] + 0.03 * t)
+                                   + 16.0 * np.cos(2 * np.pi * fy[c] * yy / height + ph[c, 1] - 0.02 * t) + bl * (1.0 - 0.15 * c))
+                img += rng.integers(-2, 3, img.shape).astype(np.float32)
+                out[b, t] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        elif kind == "saturated":
+            cells = rng.integers(0, 2, (height // 24 + 3, width // 32 + 3, 3), dtype=np.uint8) * np.uint8(255)
+            big = np.repeat(np.repeat(cells, 24, axis=0), 32, axis=1)
+            for t in range(n_frames):
+                dy, dx = (3 * t) % 24, (3 * t) % 32
+                out[b, t] = big[dy:dy + height, dx:dx + width]
+        else:
+            raise ValueError(f"unknown kind {kind!r}")
+    if kind == "jitter":
+        hts = mask_heights(seed, n_clips, n_frames, 80, 140)
+        hts[:, 3 % n_frames] = 0
+        hts[:, 5 % n_frames] = height
+        for b in range(n_clips):
+            for t in range(n_frames):
+                out[b, t, :hts[b, t]] = 0
+    else:
+        out[:, :, :mask_rows] = 0
+    return out
+
+
 def mask_heights(seed, n_clips, n_frames, lo, hi):
     """Per-frame mask heights of synth_frames(..., mask_jitter=(lo, hi)), i.i.d. uniform in lo..hi (harsher than video)."""
     return np.random.default_rng([seed, 0x6A17]).integers(lo, hi + 1, (n_clips, n_frames))
@@ -223,6 +275,42 @@ def synth_text(seed, n_clips, n_words, d=768):
 
 def synth_boundaries(n_clips, n_words, stride=15, length=10):
     return [[[f"w{i}", stride * i, stride * i + length] for i in range(n_words)] for _ in range(n_clips)]
+
+
+def synth_ragged_clip(seed, n_frames, n_words, d=768):
+    """One clip of a RAGGED dataset (AVS clips are 25..220 frames, 3..12 words, the last word ends with the clip): GestSync
+    features (T,1024) ~ N(0,1), mel (4T,80) ~ N(8,2.5), XLM-R stand-in states for words of 1..3 sub-words (the LAST word always
+    has 2 or 3, so its row range matters: jegal.py:168-171 runs it to the end of the padded batch), and word boundaries that
+    tile frames 0..T-1 with the last word ending on frame T-1.  Returns a dict with the pieces the drivers read."""
+    rng = np.random.default_rng(seed)
+    T, W = int(n_frames), int(n_words)
+    feats = rng.standard_normal((T, 1024)).astype(np.float32)
+    mel = (8.0 + 2.5 * rng.standard_normal((4 * T, 80))).astype(np.float32)
+    nsub = rng.integers(1, 4, W)
+    nsub[-1] = rng.integers(2, 4)
+    L = int(nsub.sum()) + 2
+    states = rng.standard_normal((L, d)).astype(np.float32)
+    ids = np.zeros(L, np.int64)
+    offsets = np.zeros((L, 2), np.int64)
+    pos = 1
+    for w in range(W):
+        for j in range(int(nsub[w])):
+            ids[pos] = 1000 + 7 * w + j
+            offsets[pos] = (3 * j, 3 * j + 3)          # first sub-word of a word: offset[0] == 0 (jegal.py:148-150)
+            pos += 1
+    ids[pos] = 2
+    mask = np.ones(L, np.int64)
+    # word w covers frames cuts[w] .. cuts[w+1]-1 (gaps of 0..2 frames inside the clip, none at the end)
+    cuts = np.sort(rng.choice(np.arange(1, T), W - 1, replace=False)) if W > 1 else np.array([], np.int64)
+    cuts = np.concatenate(([0], cuts, [T]))
+    wbs = []
+    for w in range(W):
+        s, e = int(cuts[w]), int(cuts[w + 1]) - 1
+        if w < W - 1 and e - s >= 3:
+            e -= int(rng.integers(0, 3))
+        wbs.append([f"w{w}", s, e])
+    return {"feats": feats, "mel": mel, "states": states, "mask": mask, "ids": ids, "offsets": offsets, "word_boundaries": wbs,
+            "phrase": " ".join(w[0] for w in wbs)}
 
 
 def planted_retrieval(seed, n, d=512, noise=0.2):

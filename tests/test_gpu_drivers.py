@@ -185,3 +185,142 @@ def test_ragged_batches_by_last_frame_padding_are_exact():
         solo = gs.extract_clip_feats(torch.from_numpy(c).cuda())[0].cpu()
         r = float((out[i, :lens[i]] - solo).norm() / solo.norm())
         assert r < 1e-3, (i, r)
+
+
+def _ragged_dataset(tmp_path, lens, words, seed0=500):
+    """A ragged AVS-like dataset on disk in the drivers' formats; returns (csv, dirs, clips)."""
+    import pandas as pd
+    feat_dir, video_dir, res_dir = (str(tmp_path / d) for d in ("feats", "videos", "res"))
+    rows, clips = [], []
+    for i, (T, W) in enumerate(zip(lens, words)):
+        vid, track = f"vid{i:02d}_1.0-2.0", "00000"
+        c = synth.synth_ragged_clip(seed0 + i, T, W)
+        clips.append(c)
+        os.makedirs(os.path.join(feat_dir, vid), exist_ok=True)
+        os.makedirs(os.path.join(video_dir, vid), exist_ok=True)
+        np.save(os.path.join(feat_dir, vid, track + ".npy"), c["feats"])
+        np.save(os.path.join(video_dir, vid, track + ".mel.npy"), c["mel"])
+        np.savez(os.path.join(video_dir, f"{vid}__{track}.npz"), states=c["states"], mask=c["mask"], ids=c["ids"], offsets=c["offsets"])
+        wb = c["word_boundaries"]
+        rows.append({"video_id": vid, "filename": f"{vid}/{track}", "phrase": c["phrase"], "word_boundaries": str(wb),
+                     "target_word_boundary": str(wb[(3 * i + 1) % W])})
+    csv = str(tmp_path / "avs.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    return csv, (feat_dir, video_dir, res_dir), clips, rows
+
+
+def _oracle_alone(jsd, c, mod):
+    """The reference pipeline on ONE clip alone in its batch (extract_jegal_embs.py:141 runs batch_size=1)."""
+    vis = torch.from_numpy(c["feats"])[None] if "v" in mod else None
+    pack = (c["states"][None], c["mask"][None], [c["phrase"].split(" ")], c["ids"][None], c["offsets"][None]) if "t" in mod else None
+    mel = torch.from_numpy(c["mel"])[None] if "a" in mod else None
+    with torch.no_grad():
+        out = O.jegal_forward_inference(jsd, visual_feats=vis, visual_mask=None if vis is None else torch.ones(1, vis.shape[1]), text=pack,
+                                        audio=mel, audio_mask=None, word_boundaries=[c["word_boundaries"]])
+    g = cemb = None
+    if vis is not None and (pack is not None or mel is not None):
+        g, cemb = out
+    elif vis is not None:
+        g = out
+    else:
+        cemb = out
+    return (None if g is None else O.l2_normalize(g[0]).numpy(), None if cemb is None else O.l2_normalize(cemb[0]).numpy())
+
+
+@pytest.mark.parametrize("mod", ["vta", "ta", "a", "t"])
+def test_extract_jegal_embs_is_batch_invariant_on_ragged_clips(tmp_path, mod):
+    """the reference's dataset driver runs ONE clip per step (evaluation/extract_jegal_embs.py:141); this
+    driver batches 16.  Sixteen ragged clips (T 25..220, W 3..12, every last word multi-sub-word and ending on the clip's last
+    frame) in one padded batch: every .pkl row must be what the oracle gives for that clip ALONE (< 1e-3), the last content row
+    included -- it is the one that the padded text length (jegal.py:168-171) and the zero-padded audio conv stack (jegal.py:41-63)
+    used to change by 0.37 / 3.5e-2 -- and the retrieval / spotting numbers of the written .pkl files equal those of the
+    per-clip oracle pipeline."""
+    rng = np.random.default_rng(11)
+    lens = [25, 220, 150, 31, 77, 26, 199, 64, 120, 48, 33, 181, 90, 55, 140, 29]
+    words = [3, 12, 10, 4, 7, 3, 11, 6, 9, 5, 4, 12, 8, 5, 10, 3]
+    csv, (feat_dir, video_dir, res_dir), clips, rows = _ragged_dataset(tmp_path, lens, words)
+    assert drivers.main(["extract_jegal_embs", "--file_path", csv, "--checkpoint_path", "synthetic", "--res_dir", res_dir,
+                         "--video_dir", video_dir, "--feature_dir", feat_dir, "--text_states_dir", video_dir,
+                         "--modalities", mod, "--batch_size", "16"]) == 0
+    pk = os.path.join(res_dir, mod)
+    files = sorted(os.listdir(pk))
+    assert len(files) == 16
+    feats = [pickle.load(open(os.path.join(pk, f), "rb")) for f in files]
+    jsd = O.tensors(synth.jegal_state_dict())
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    worst_g = worst_c = worst_last = 0.0
+    ref = []
+    for c, f, T, W in zip(clips, feats, lens, words):
+        g, ce = _oracle_alone(jsd, c, mod)
+        ref.append((g, ce))
+        if g is not None:
+            assert f["gesture_emb"].shape == (T, 512)
+            worst_g = max(worst_g, rel(f["gesture_emb"], g))
+        else:
+            assert f["gesture_emb"] is None
+        assert f["content_emb"].shape == (W, 512)
+        worst_c = max(worst_c, rel(f["content_emb"], ce))
+        worst_last = max(worst_last, float(np.abs(f["content_emb"][-1] - ce[-1]).max()))
+    print(f"\n[{mod}] 16 ragged clips in one batch vs the oracle on each clip alone: gesture {worst_g:.2e}, content {worst_c:.2e}, "
+          f"last word max-abs {worst_last:.2e}")
+    assert worst_g < 1e-3 and worst_c < 1e-3 and worst_last < 1e-3
+    if mod != "vta":
+        return
+    # metrics of the written pkls == the per-clip oracle pipeline's
+    res = drivers.cmd_evaluate_retrieval(["--path", pk])
+    gv = [g.mean(axis=0) for g, _ in ref]
+    cv = [c.mean(axis=0) for _, c in ref]
+    assert res["Content to Gesture"] == O.compute_metrics(O.similarity_matrix(cv, gv).numpy())
+    assert res["Gesture to Content"] == O.compute_metrics(O.similarity_matrix(gv, cv).numpy())
+    acc = drivers.cmd_evaluate_spotting(["--path", pk])
+    wbs = [c["word_boundaries"] for c in clips]
+    tg = [wb.index(eval(r["target_word_boundary"])) for wb, r in zip(wbs, rows)]
+    assert acc == pytest.approx(O.spotting_accuracy([g for g, _ in ref], [c for _, c in ref], wbs, tg))
+    # and the batch size does not matter: the same files from batches of 1 (the reference's own setting) and of 5
+    for bs in ("1", "5"):
+        rd = res_dir + "_bs" + bs
+        assert drivers.main(["extract_jegal_embs", "--file_path", csv, "--checkpoint_path", "synthetic", "--res_dir", rd,
+                             "--video_dir", video_dir, "--feature_dir", feat_dir, "--text_states_dir", video_dir,
+                             "--modalities", mod, "--batch_size", bs]) == 0
+        for fn, f16, (g, ce) in zip(files, feats, ref):
+            f1 = pickle.load(open(os.path.join(rd, mod, fn), "rb"))
+            # (the content path takes the same kernels at every batch size; a 25-frame clip ALONE takes the register-staged GEMM for
+            # its gesture rows, M < 128, whose fp32 summation order differs: path-to-path noise, both within 1e-3 of the oracle)
+            assert rel(f1["content_emb"], f16["content_emb"]) < 2e-4, (bs, fn)
+            assert rel(f1["content_emb"], ce) < 1e-3 and rel(f1["gesture_emb"], g) < 1e-3, (bs, fn)
+
+
+def test_forward_inference_default_keeps_the_reference_semantics_at_b_gt_1():
+    """The facade (not the driver) mirrors models/jegal.py at B > 1, padded-length dependence included: the default call on a
+    padded batch equals the oracle on the SAME padded batch; per_clip=True equals the oracle on each clip alone."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.jegal import JEGAL
+    eng = Engine.get("cuda:0")
+    jg = JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    jsd = O.tensors(synth.jegal_state_dict())
+    a, b = synth.synth_ragged_clip(900, 30, 3), synth.synth_ragged_clip(901, 34, 6)
+    L = max(len(a["ids"]), len(b["ids"]))
+    st = np.zeros((2, L, 768), np.float32); tm = np.zeros((2, L), np.int64); ids = np.ones((2, L), np.int64); offs = np.zeros((2, L, 2), np.int64)
+    for i, c in enumerate((a, b)):
+        l = len(c["ids"])
+        st[i, :l], tm[i, :l], ids[i, :l], offs[i, :l] = c["states"], c["mask"], c["ids"], c["offsets"]
+    mel = np.zeros((2, 4 * 34, 80), np.float32)
+    mel[0, :120], mel[1] = a["mel"], b["mel"]
+    tb = [a["phrase"].split(" "), b["phrase"].split(" ")]
+    wbs = [a["word_boundaries"], b["word_boundaries"]]
+    pack = (torch.from_numpy(st), torch.from_numpy(tm), tb, ids, offs)
+    with torch.no_grad():
+        ref_batch = O.jegal_forward_inference(jsd, text=(st, tm, tb, ids, offs), audio=torch.from_numpy(mel), word_boundaries=wbs)
+    got = jg.forward_inference(text=pack, audio=torch.from_numpy(mel), word_boundaries=wbs).cpu()
+    rel = lambda x, y: float((x - y).norm() / y.norm())
+    assert rel(got[0, :3], ref_batch[0, :3]) < 1e-3 and rel(got[1], ref_batch[1]) < 1e-3
+    got_pc = jg.forward_inference(text=pack, audio=torch.from_numpy(mel), word_boundaries=wbs, audio_lens=[120, 136], per_clip=True).cpu()
+    _, alone = _oracle_alone(jsd, a, "ta")
+    with torch.no_grad():
+        alone_raw = O.jegal_forward_inference(jsd, text=(a["states"][None], a["mask"][None], [tb[0]], a["ids"][None], a["offsets"][None]),
+                                              audio=torch.from_numpy(a["mel"])[None], word_boundaries=[wbs[0]])[0]
+    assert rel(got_pc[0, :3], alone_raw) < 1e-3
+    # the two semantics really differ on the last word of the shorter clip (else this test proves nothing)
+    assert float((ref_batch[0, 2] - alone_raw[2]).abs().max()) > 1e-2
+    with pytest.raises(ValueError):
+        jg.forward_inference(text=pack, audio=torch.from_numpy(mel), word_boundaries=wbs, per_clip=True)       # audio_lens missing

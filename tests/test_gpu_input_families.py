@@ -1,0 +1,86 @@
+"""Frames -> embedding parity against the oracle on inputs that are NOT uniform noise.
+
+Every frames -> embedding oracle comparison of rounds 1-3 drew its clips from synth.synth_frames (noise under a 110-row mask) -- the
+distribution the default precision mode's bias corrections are calibrated on (api.hip, calibrate_impl).  The reference's inputs
+are natural crops (inference_embs.py:235-286): smooth, low contrast, saturated regions, a mask that follows the chin per frame.
+Three seeded families (synth.synth_frames_structured), two full-length clips each, default mode (JG_PREC_FP16_BC, calibrated on
+the built-in noise clips) and the calibration-free JG_PREC_FP16_W2, measured errors printed."""
+import numpy as np
+import pytest
+import torch
+
+import jegal_oracle as O
+from jegal_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+T = 150
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def oracle_sd():
+    return O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from jegal_amd._lib import Engine, PREC_FP16_BC, PREC_FP16_W2
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    out = {}
+    for name, mode in (("fp16_bc", PREC_FP16_BC), ("fp16_w2", PREC_FP16_W2)):
+        e = Engine(0, precision=mode)
+        GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+        JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+        out[name] = e
+    yield out
+    for e in out.values():
+        e.close()
+
+
+@pytest.mark.parametrize("kind", ["smooth", "saturated", "jitter"])
+def test_structured_clips_vs_oracle(engines, oracle_sd, kind):
+    gsd, jsd = oracle_sd
+    frames = synth.synth_frames_structured(4100, 2, T, kind)
+    refs = []
+    with torch.no_grad():
+        for b in range(2):
+            f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+            refs.append((f.numpy(), O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy()))
+    dev = torch.from_numpy(frames).cuda()
+    for name, e in engines.items():
+        emb = e.extract_gesture(dev).cpu().numpy()
+        feats = e.gestsync_clip(dev).cpu().numpy()
+        for b in range(2):
+            r, mx, rf = rel(emb[b], refs[b][1]), float(np.abs(emb[b] - refs[b][1]).max()), rel(feats[b], refs[b][0])
+            print(f"\n[{kind}] {name} clip {b}: embedding rel-L2 {r:.3e} max-abs {mx:.3e} | GestSync feats rel-L2 {rf:.3e}", end="")
+            assert np.isfinite(emb[b]).all()
+            assert r < TOL and mx < TOL, (kind, name, b, r, mx)
+            assert rf < TOL, (kind, name, b, rf)
+
+
+def test_calibrating_on_structured_clips_keeps_noise_clips_in_tolerance(oracle_sd):
+    """The other direction of the calibration question: bias corrections recorded on SMOOTH clips (jg_calibrate_gesture), tested
+    on the noise clips of BASELINE configs[1] and on the saturated family."""
+    from jegal_amd._lib import Engine, PREC_FP16_BC
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    gsd, jsd = oracle_sd
+    e = Engine(0, precision=PREC_FP16_BC)
+    GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+    e.calibrate(torch.from_numpy(synth.synth_frames_structured(77, 2, 24, "smooth")).cuda())
+    for kind, fr in (("noise", synth.synth_frames(1234, 1, T)), ("saturated", synth.synth_frames_structured(4100, 1, T, "saturated"))):
+        with torch.no_grad():
+            f = O.gestsync_clip_feats(gsd, torch.from_numpy(fr[0].astype(np.float32) / np.float32(255.0)))
+            ref = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy()
+        emb = e.extract_gesture(torch.from_numpy(fr).cuda())[0].cpu().numpy()
+        r = rel(emb, ref)
+        print(f"\ncalibrated on smooth clips, tested on {kind}: rel-L2 {r:.3e}", end="")
+        assert r < TOL, (kind, r)
+    e.close()

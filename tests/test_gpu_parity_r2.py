@@ -520,8 +520,25 @@ rk, ti = eng.sim_rank(eng.l2norm(torch.from_numpy(c)), eng.l2norm(torch.from_num
 ref = M.metrics_from_ranks(rk.cpu().numpy(), ti.cpu().numpy())
 assert m == ref, (m, ref)
 assert 0.0 < m["R1"] < 1.0
+# config 5: spotting sharded by clips (4000 clips, W = 30), two counters all-reduced -- equals the single-rank call
+import torch.distributed as td
+gest, cont, bounds, targets = synth.planted_spotting(1238, 4000)
+lo, hi = jdist.shard_range(4000)
+acc = M.spotting_accuracy(gest[lo:hi], cont[lo:hi], bounds[lo:hi], targets[lo:hi], engine=eng)
+pred, score = eng.spot(torch.from_numpy(np.concatenate(gest)), torch.from_numpy(np.concatenate(cont)), M._offsets(gest), M._offsets(cont), targets)
+c1, n1 = M.spotting_counts(pred.cpu().numpy(), score.cpu().numpy(), bounds, targets)
+assert n1 == 4000 and acc == 100.0 * c1 / n1 and 10.0 < acc < 90.0, (acc, c1)
+# ASD sharded by queries, four counters all-reduced
+contents, positives, negatives = synth.planted_asd(11, 301)
+q = np.stack([np.asarray(c, np.float32).mean(0) for c in contents])
+cands = [np.stack([np.asarray(p_, np.float32).mean(0)] + [np.asarray(g_, np.float32).mean(0) for g_ in negs]) for p_, negs in zip(positives, negatives)]
+lo, hi = jdist.shard_range(301)
+a = M.asd_accuracy(q[lo:hi], cands[lo:hi], engine=eng)
+pr = eng.asd(torch.from_numpy(q), torch.cat([torch.from_numpy(c) for c in cands]).cuda(), M._offsets(cands)).cpu().numpy()
+c2, c4, c6, nq = M.asd_counts(pr)
+assert nq == 301 and a == (c2 / nq, c4 / nq, c6 / nq), (a, c2, c4, c6)
 jdist.barrier()
-print("rank", r, "ok", m["R1"], m["MR"])
+print("rank", r, "ok", m["R1"], m["MR"], acc, a)
 """
 
 
@@ -549,7 +566,8 @@ def _run_two(script):
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_two_rank_sharded_retrieval_on_gpu(tmp_path, backend):
     """Config 4's exchange with jg_sim_rank on the device: 2 ranks, queries sharded ceil(N/2), gallery all-gathered,
-    R@K / MR identical to the single-rank result.  nccl (RCCL over xGMI) needs 2 GPUs; with one GPU the same test
+    R@K / MR identical to the single-rank result; config 5's sharded spotting (4000 clips) and the sharded ASD evaluation with
+    their counter all-reduce, identical to the single-rank calls.  nccl (RCCL over xGMI) needs 2 GPUs; with one GPU the same test
     runs over gloo with both ranks on device 0 (host-staged gather)."""
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")

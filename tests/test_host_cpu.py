@@ -212,6 +212,8 @@ def test_cli_drivers_pick_the_calibration_free_mode_for_real_checkpoints():
     assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 1
     assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/gestsync.pth"]) == 3
     assert pick_precision(NS(precision=0, calibrate_frames=None), ["/ckpt/jegal.pth"]) == 0
+    # calibration clips only count when the command can run the calibration (needs GestSync: extract_jegal_embs cannot)
+    assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/jegal.pth"], can_calibrate=False) == 1
 
 
 def test_masked_packer_layout():
@@ -238,3 +240,95 @@ def test_masked_packer_layout():
     pk.reset()
     with pytest.raises(ValueError):
         pk.add(clips[0], 271)
+
+
+def test_word_segments_per_clip_equal_the_oracle_on_each_clip_alone():
+    """Host side of the batch-invariant content path: with per-sample lengths the row ranges of a padded
+    batch are those the reference's word pooling (jegal.py:131-252, restated in the oracle) takes on each clip ALONE; without
+    them the last word runs to the padded length (the reference's B > 1 behaviour, jegal.py:168-171)."""
+    import jegal_oracle as O
+    from jegal_amd import synth
+    from jegal_amd.jegal import audio_word_segments, text_word_segments
+    lens, words = [25, 40, 31], [3, 7, 4]
+    clips = [synth.synth_ragged_clip(40 + i, T, W) for i, (T, W) in enumerate(zip(lens, words))]
+    L = max(len(c["ids"]) for c in clips)
+    ids = np.ones((3, L), np.int64); offs = np.zeros((3, L, 2), np.int64); emb = np.zeros((3, L, 8), np.float32)
+    rng = np.random.default_rng(0)
+    for i, c in enumerate(clips):
+        l = len(c["ids"])
+        ids[i, :l], offs[i, :l] = c["ids"], c["offsets"]
+        emb[i] = rng.standard_normal((L, 8))
+    tb = [c["phrase"].split(" ") for c in clips]
+    segs, invalid = text_word_segments(ids, offs, tb, lengths=[len(c["ids"]) for c in clips])
+    assert invalid == []
+    for i, c in enumerate(clips):
+        l = len(c["ids"])
+        alone, _ = O.word_level_text(torch.from_numpy(emb[i:i + 1, :l]), [tb[i]], ids[i:i + 1, :l], offs[i:i + 1, :l])
+        mine = np.stack([emb[i, lo:hi].mean(0) for lo, hi in segs[i]])
+        np.testing.assert_allclose(mine, alone[0].numpy(), rtol=1e-6, atol=1e-6)
+        assert segs[i][-1][1] == l                                   # the last word swallows </s>, not the pads
+    padded, _ = text_word_segments(ids, offs, tb)
+    assert padded[0][-1][1] == L and padded[0][:-1] == segs[0][:-1]  # only the last word differs
+    # audio: slices are clipped to the clip's own audio steps
+    wbs = [c["word_boundaries"] for c in clips]
+    a = audio_word_segments(wbs, lens)
+    for i in range(3):
+        assert a[i][-1] == (wbs[i][-1][1], lens[i]) and all(hi - lo == w[2] - w[1] + 1 for (lo, hi), w in zip(a[i], wbs[i]))
+    long_wb = [[["w0", 0, 10], ["w1", 11, 60]]]
+    assert audio_word_segments(long_wb, [30])[0][-1] == (11, 30) and audio_word_segments(long_wb, 40)[0][-1] == (11, 40)
+    with pytest.raises(ValueError):
+        text_word_segments(ids, offs, tb, lengths=[0, 5, 5])
+
+
+_WORKER_SPOT_ASD = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+from jegal_amd import dist as jdist, synth, metrics as M
+import jegal_oracle as O
+jdist.init_from_env("gloo")
+r, w = jdist.rank(), jdist.world_size()
+assert w == 2
+# ---- spotting (config 5 shape, small): every rank scores ITS contiguous block, two counters are all-reduced
+n = 41
+gest, cont, bounds, targets = synth.planted_spotting(1238, n, n_frames=60, n_words=8, noise=3.0)
+lo, hi = jdist.shard_range(n)
+pred, score = [], []
+for i in range(lo, hi):                           # stand-in for jg_spot on the CPU test box: the oracle's argmax / probability
+    _, p, s = O.spotting_correct(gest[i], cont[i], bounds[i], targets[i])
+    pred.append(p); score.append(s)
+correct, total = M.reduce_counts(M.spotting_counts(pred, score, bounds[lo:hi], targets[lo:hi]))
+assert total == n
+acc = 100.0 * correct / total
+ref = O.spotting_accuracy(gest, cont, bounds, targets)
+assert abs(acc - ref) < 1e-9 and 5.0 < acc < 95.0, (acc, ref)
+# ---- ASD: queries sharded, four counters all-reduced
+contents, positives, negatives = synth.planted_asd(7, 37)
+(ref2, ref4, ref6), ref_pred = O.asd_accuracy(contents, positives, negatives)
+lo, hi = jdist.shard_range(len(contents))
+c2, c4, c6, nq = M.reduce_counts(M.asd_counts(ref_pred[lo:hi]))
+assert nq == len(contents)
+assert (c2 / nq, c4 / nq, c6 / nq) == (ref2, ref4, ref6)
+# a rank without a single item still takes part in the reduction
+z = M.reduce_counts([0, 0] if r == 1 else [3, 5])
+assert z == [3, 5]
+jdist.barrier()
+print("rank", r, "ok", acc, ref2)
+"""
+
+
+def test_two_rank_gloo_sharded_spotting_and_asd(tmp_path):
+    """SURVEY 8e / VERDICT r3 item 5: spotting and ASD shard by clips / queries with a counter all-reduce only.  World-size-2 gloo
+    run of jegal_amd.metrics' host logic (spotting_counts / asd_counts / reduce_counts) with the oracle standing in for the device
+    kernels: the sharded accuracies equal the single-rank oracle's exactly."""
+    script = tmp_path / "worker_spot.py"
+    script.write_text(_WORKER_SPOT_ASD.format(root=ROOT))
+    for attempt in range(3):
+        outs = _run_two_ranks(script)
+        if all(rc == 0 for rc, _ in outs):
+            break
+        text = "\n".join(o for _, o in outs)
+        if "AssertionError" in text or attempt == 2:
+            raise AssertionError(text)
+    for rc, out in outs:
+        assert " ok" in out
