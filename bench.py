@@ -476,6 +476,32 @@ def main():
                 eng.extract_gesture(frames, out)
                 assert np.array_equal(emb_m, out.cpu().numpy()), "masked upload differs from the resident path"
                 del st
+                # source-resolution upload: the decoder's 228x314 frames (reference samples/sample1.avi, inference_embs.py:255-276
+                # resizes them to 270x480 on the host) with their mask rows; mask + resize run on the upload stream (jg_mask_resize_packed)
+                SH, SW = 228, 314
+                rng_s = np.random.default_rng(4321)
+                src = rng_s.integers(0, 256, (args.clips, FRAMES, SH, SW, 3), dtype=np.uint8)
+                my_src = int(round(109 * SH / 270.0))                      # the 110-row mask of the synthetic crops at source scale
+                st = GestureStreamer(eng, args.clips, FRAMES, source_hw=(SH, SW))
+                for s_ in range(2):
+                    for b in range(args.clips):
+                        st.packer[s_].add(src[b], my_src)
+                for _ in st.run_filled(lambda pk, k: args.clips if k < 2 else 0):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                got, emb_s = 0, None
+                for _, emb in st.run_filled(lambda pk, k: args.clips if k < nb else 0):
+                    got += emb.shape[0]
+                    emb_s = emb
+                extras["pcie_source_clips_per_s"] = got / (time.perf_counter() - t0)
+                extras["pcie_source_bytes"] = st.packer[0].used
+                crops = torch.stack([eng.mask_resize(torch.from_numpy(src[b]), [my_src] * FRAMES) for b in range(args.clips)])
+                eng.extract_gesture(crops, out)
+                torch.cuda.synchronize()
+                assert np.array_equal(emb_s, out.cpu().numpy()), "source-resolution upload differs from load_rgb_masked_frames + the resident path"
+                extras["pcie_source_hw"] = [SH, SW]
+                del st, crops, src
     jdist.barrier()
 
     if rank == 0:
@@ -571,6 +597,14 @@ def main():
                     "value": extras["pcie_masked_clips_per_s"], "unit": "clips/s", "bytes_per_batch": extras["pcie_masked_bytes"],
                     "bytes_per_batch_dense": args.clips * FRAMES * 270 * 480 * 3, "equals_resident_path": True,
                     "what": "only the rows below each clip's face mask cross the link (GestureStreamer(masked=True)), jg_unpack_masked rebuilds the batch on the upload stream"}
+            if "pcie_source_clips_per_s" in extras:
+                res["pcie_inclusive"]["source_res"] = {
+                    "value": extras["pcie_source_clips_per_s"], "unit": "clips/s", "source_hw": extras["pcie_source_hw"],
+                    "bytes_per_batch": extras["pcie_source_bytes"], "bytes_per_batch_dense": args.clips * FRAMES * 270 * 480 * 3,
+                    "equals_resident_path": True,
+                    "what": "decoder-resolution frames (228x314 as in the reference's samples/sample1.avi), only the source rows below each frame's mask "
+                            "cross the link (GestureStreamer(source_hw=...)); face mask + cv2-style bilinear resize to 270x480 on the upload stream "
+                            "(jg_mask_resize_packed); bit-identical to load_rgb_masked_frames + the resident path"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(frames_host[:2])
         else:

@@ -145,10 +145,19 @@ int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const 
 
 /* Masked crops in fewer bytes (the host link, not the GPU, bounds a streamed extraction: DESIGN.md section 7): the reference blanks
  * rows 0..y2+15 of every crop (inference_embs.py:264-270), so a producer ships only the rows BELOW each frame's mask.
- * packed: those rows of all frames back to back (device); row0 (n_frames) int32 device: first kept row of each frame (0..270);
- * offsets (n_frames) int64 device: byte offset of that row in `packed` (multiples of 16) -> dst (n_frames,270,480,3) uint8 with
- * the rows above row0 zero: exactly the crop load_rgb_masked_frames returns, ready for jg_gestsync_clip / jg_extract_gesture. */
-int jg_unpack_masked(jg_handle* h, const uint8_t* packed, const int32_t* row0, const int64_t* offsets, int n_frames, uint8_t* dst);
+ * packed: those rows of all frames back to back (device), packed_bytes its size; row0 (n_frames) int32 device: first kept row of
+ * each frame (0..270); offsets (n_frames) int64 device: byte offset of that row in `packed` (multiples of 16) -> dst
+ * (n_frames,270,480,3) uint8 with the rows above row0 zero: exactly the crop load_rgb_masked_frames returns, ready for
+ * jg_gestsync_clip / jg_extract_gesture.  Metadata is validated ON THE DEVICE (it lives there): a frame whose row0 is outside
+ * 0..270 or whose offset is negative, not a multiple of 16 or runs past packed_bytes comes out all zero, nothing is read. */
+int jg_unpack_masked(jg_handle* h, const uint8_t* packed, int64_t packed_bytes, const int32_t* row0, const int64_t* offsets, int n_frames, uint8_t* dst);
+/* The same at SOURCE resolution: the reference decodes e.g. 228x314 / 294x294 crops and resizes them to 270x480 on the host
+ * (inference_embs.py:255-276) -- shipping the decoder's frames moves up to 1.8x fewer bytes than shipping the resized crops, and the
+ * rows the mask blanks (source rows 0..mask_y) need not cross the link at all.  packed: per frame f the source rows
+ * max(mask_y[f]+1, 0) .. H-1 (mask_y = -1, no face: the whole frame), (H - row0) * W * 3 bytes starting at offsets[f];
+ * -> dst (T,270,480,3) uint8 = jg_mask_resize of the full frames.  A frame whose rows would run past packed_bytes comes out zero. */
+int jg_mask_resize_packed(jg_handle* h, const uint8_t* packed, int64_t packed_bytes, const int64_t* offsets, int T, int H, int W,
+                          const int32_t* mask_y, uint8_t* dst);
 
 /* ---- JEGAL (models/jegal.py) ---------------------------------------------------------------- */
 /* forward_gestures (jegal.py:78-92) [+ proj_op_align_gesture, jegal.py:381 when align != 0]:

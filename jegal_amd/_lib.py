@@ -44,7 +44,8 @@ _SIGS = {
     "jg_audio_len": [_I],
     "jg_logmel": [_P, _P, _I, _I, _P, _P],
     "jg_mask_resize": [_P, _P, _I, _I, _I, _P, _P],
-    "jg_unpack_masked": [_P, _P, _P, _P, _I, _P],
+    "jg_unpack_masked": [_P, _P, ctypes.c_int64, _P, _P, _I, _P],
+    "jg_mask_resize_packed": [_P, _P, ctypes.c_int64, _P, _I, _I, _I, _P, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
     "jg_xlmr_encode": [_P, _P, _P, _I, _I, _P],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
@@ -337,13 +338,26 @@ class Engine:
         return out
 
     def unpack_masked(self, packed, row0, offsets, dst):
-        """packed uint8 (bytes,) / row0 int32 (F,) / offsets int64 (F,) device tensors -> dst (F,270,480,3) uint8 (written in place)."""
+        """packed uint8 (bytes,) / row0 int32 (F,) / offsets int64 (F,) device tensors -> dst (F,270,480,3) uint8 (written in place).
+        offsets must be multiples of 16; the kernel writes a frame as zeros instead of reading it when its metadata points outside
+        `packed` (row0 outside 0..270, misaligned / negative offset, rows past the end)."""
         self._bind_stream()
         F = row0.numel()
         if (packed.dtype != torch.uint8 or row0.dtype != torch.int32 or offsets.dtype != torch.int64 or dst.dtype != torch.uint8
-                or offsets.numel() != F or dst.numel() != F * 270 * 480 * 3 or not dst.is_contiguous()):
+                or offsets.numel() != F or dst.numel() != F * 270 * 480 * 3 or not dst.is_contiguous() or not packed.is_contiguous()):
             raise ValueError("unpack_masked: packed uint8, row0 int32 (F), offsets int64 (F), dst uint8 (F,270,480,3)")
-        self._ck(self.lib.jg_unpack_masked(self.h, _ptr(packed), _ptr(row0), _ptr(offsets), F, _ptr(dst)))
+        self._ck(self.lib.jg_unpack_masked(self.h, _ptr(packed), packed.numel(), _ptr(row0), _ptr(offsets), F, _ptr(dst)))
+        return dst
+
+    def mask_resize_packed(self, packed, offsets, mask_y, H, W, dst):
+        """Source-resolution frames with only the rows below each frame's mask shipped (jg_mask_resize_packed): packed uint8 (bytes,),
+        offsets int64 (F,), mask_y int32 (F,) device tensors -> dst (F,270,480,3) uint8 (written in place)."""
+        self._bind_stream()
+        F = mask_y.numel()
+        if (packed.dtype != torch.uint8 or mask_y.dtype != torch.int32 or offsets.dtype != torch.int64 or dst.dtype != torch.uint8
+                or offsets.numel() != F or dst.numel() != F * 270 * 480 * 3 or not dst.is_contiguous() or not packed.is_contiguous()):
+            raise ValueError("mask_resize_packed: packed uint8, offsets int64 (F), mask_y int32 (F), dst uint8 (F,270,480,3)")
+        self._ck(self.lib.jg_mask_resize_packed(self.h, _ptr(packed), packed.numel(), _ptr(offsets), F, int(H), int(W), _ptr(mask_y), _ptr(dst)))
         return dst
 
     def logmel(self, wav, mel_basis):

@@ -1524,11 +1524,20 @@ int jg_mask_resize(jg_handle* h, const uint8_t* src, int T, int H, int W, const 
     return timed(h, JG_ST_MISC, [&] { return launch_mask_resize(src, T, H, W, mask_y, dst, h->stream); });
 }
 
-int jg_unpack_masked(jg_handle* h, const uint8_t* packed, const int32_t* row0, const int64_t* offsets, int n_frames, uint8_t* dst) {
+int jg_unpack_masked(jg_handle* h, const uint8_t* packed, int64_t packed_bytes, const int32_t* row0, const int64_t* offsets, int n_frames, uint8_t* dst) {
     ENTER(h);
-    if (!packed || !row0 || !offsets || !dst || n_frames <= 0) JG_FAIL(h, JG_ERR_ARG, "bad unpack_masked arguments");
+    if (!packed || !row0 || !offsets || !dst || n_frames <= 0 || packed_bytes < 0) JG_FAIL(h, JG_ERR_ARG, "bad unpack_masked arguments");
     static_assert(sizeof(long long) == sizeof(int64_t), "offset type");
-    return timed(h, JG_ST_MISC, [&] { return launch_unpack_masked(packed, row0, reinterpret_cast<const long long*>(offsets), n_frames, dst, h->stream); });
+    return timed(h, JG_ST_MISC, [&] { return launch_unpack_masked(packed, row0, reinterpret_cast<const long long*>(offsets), n_frames, dst, h->stream,
+                                                                   (long long)packed_bytes); });
+}
+
+int jg_mask_resize_packed(jg_handle* h, const uint8_t* packed, int64_t packed_bytes, const int64_t* offsets, int T, int H, int W,
+                          const int32_t* mask_y, uint8_t* dst) {
+    ENTER(h);
+    if (!packed || !offsets || !mask_y || !dst || T <= 0 || H <= 0 || W <= 0 || packed_bytes < 0) JG_FAIL(h, JG_ERR_ARG, "bad mask_resize_packed arguments");
+    return timed(h, JG_ST_MISC, [&] { return launch_mask_resize(packed, T, H, W, mask_y, dst, h->stream, reinterpret_cast<const long long*>(offsets),
+                                                                 (long long)packed_bytes); });
 }
 
 int jg_logmel(jg_handle* h, const float* wav, int B, int n_samples, const float* mel_basis, float* out) {

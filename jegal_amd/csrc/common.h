@@ -191,8 +191,12 @@ void engine_opts_set_timeline(EngineOpts& o, bool on);
 // ---- launchers (each returns hipGetLastError()) -----------------------------------------
 hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStream_t s);
 bool gemm_ln_fusable(const GemmArgs& a);
-hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s);
-hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s);
+// packed_bytes >= 0: frames whose metadata points outside [0, packed_bytes) or is misaligned come out zero instead of being read
+hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s,
+                                long long packed_bytes = -1);
+// offs != nullptr: packed source -- frame f's rows max(mask_y[f] + 1, 0) .. H-1 start at src + offs[f] (src_bytes = size of src)
+hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s,
+                              const long long* offs = nullptr, long long src_bytes = 0);
 
 hipError_t launch_stack_frames(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc,
                                int B, int T, int pad, int H, int W, f16* dst, hipStream_t s);

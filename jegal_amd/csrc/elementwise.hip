@@ -388,6 +388,12 @@ __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restric
     __syncthreads();
     const int r = tid / F, f = tid - r * F;
     if (r >= TR || t0 + r >= Tm) return;
+    uint4* d = reinterpret_cast<uint4*>(out + (((long)b * Tm + t0 + r) * F + f) * 32);
+    if (t0 + r >= Tv) {                                  // beyond the clip's own frames: the next layer's zero padding
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     float acc[32];
 #pragma unroll
     for (int oc = 0; oc < 32; ++oc) acc[oc] = 0.f;
@@ -401,10 +407,8 @@ __global__ __launch_bounds__(256) void audio_conv0_kernel(const float* __restric
             for (int oc = 0; oc < 32; ++oc) acc[oc] = __builtin_fmaf(x, w[oc], acc[oc]);
         }
     f16 o[32];
-    const bool live = t0 + r < Tv;
 #pragma unroll
-    for (int oc = 0; oc < 32; ++oc) o[oc] = live ? (f16)fmaxf(acc[oc] + sb[oc], 0.f) : (f16)0.f;
-    uint4* d = reinterpret_cast<uint4*>(out + (((long)b * Tm + t0 + r) * F + f) * 32);
+    for (int oc = 0; oc < 32; ++oc) o[oc] = (f16)fmaxf(acc[oc] + sb[oc], 0.f);
 #pragma unroll
     for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<uint4*>(&o[q * 8]);
 }
@@ -655,8 +659,11 @@ hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* me
 // vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  cv2 is not installed here and the
 // pip wheels may dispatch to IPP: PARITY UNPINNED (oracle/jegal_oracle.py:mask_resize_frames is the same
 // restatement in numpy).
+// Packed source (offs != nullptr): the producer ships only the source rows BELOW each frame's mask -- frame f's rows
+// row0 = max(mask_y[f] + 1, 0) .. H-1 start at src + offs[f]; the blanked rows are never read here, so they need not exist.
+// A frame whose kept rows would end beyond `src_bytes` (bad metadata) is written as zeros instead of being read.
 __global__ void mask_resize_kernel(const uint8_t* __restrict__ src, int T, int H, int W, const int* __restrict__ mask_y,
-                                   uint8_t* __restrict__ dst) {
+                                   uint8_t* __restrict__ dst, const long long* __restrict__ offs, long long src_bytes) {
     constexpr int OH = 270, OW = 480;
     const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (idx >= (long)T * OH * OW) return;
@@ -688,7 +695,14 @@ __global__ void mask_resize_kernel(const uint8_t* __restrict__ src, int T, int H
     const int y1 = sy + 1 < 0 ? 0 : (sy + 1 < H ? sy + 1 : H - 1);
     const int x1 = sx + 1 < W ? sx + 1 : W - 1;
     const uint8_t* fr = src + (long)f * H * W * 3;
-    const bool z0 = my >= 0 && y0 <= my, z1 = my >= 0 && y1 <= my;       // blanked source rows
+    bool bad = false;
+    if (offs) {
+        const int row0 = my >= 0 ? (my + 1 < H ? my + 1 : H) : 0;
+        const long long o = offs[f];
+        bad = o < 0 || o + (long long)(H - row0) * W * 3 > src_bytes;
+        fr = src + o - (long long)row0 * W * 3;
+    }
+    const bool z0 = bad || (my >= 0 && y0 <= my), z1 = bad || (my >= 0 && y1 <= my);       // blanked source rows
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int p00 = z0 ? 0 : fr[((long)y0 * W + sx) * 3 + c], p01 = z0 ? 0 : fr[((long)y0 * W + x1) * 3 + c];
@@ -699,10 +713,123 @@ __global__ void mask_resize_kernel(const uint8_t* __restrict__ src, int T, int H
     }
 }
 
-hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s) {
+// The same arithmetic, banded (round 4: the streamed source-resolution upload runs this kernel on the upload stream next to the
+// compute, so its cost is CU time taken from the extraction): one workgroup = RB output rows of one frame.  The source rows the
+// band touches are one contiguous byte span of the frame: staged into LDS with dword loads (the span's start is aligned down, a
+// tail of < 4 bytes is loaded bytewise, nothing outside [src, src + src_bytes) is touched), the per-column (sx, a1) and per-row
+// (y0, y1, b1) coefficients are computed once per workgroup -- in double / float exactly as in mask_resize_kernel -- and the
+// output rows leave through LDS as whole 16-byte pieces (a row is 1440 B).  Results are bit-identical to mask_resize_kernel
+// (tests/test_gpu_drivers.py::test_mask_resize_matches_oracle runs both).
+constexpr int MR_RB = 6;                       // output rows per workgroup (270 = 45 bands)
+constexpr int MR_SPAN_MAX = 40 * 1024;         // LDS bytes for the source span; larger sources take the per-pixel kernel
+__global__ __launch_bounds__(256) void mask_resize_band_kernel(const uint8_t* __restrict__ src, int T, int H, int W, const int* __restrict__ mask_y,
+                                                               uint8_t* __restrict__ dst, const long long* __restrict__ offs, long long src_bytes) {
+    constexpr int OH = 270, OW = 480, RB = MR_RB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t mr_smem[];          // [orow RB*1440][span: sized by the launcher]
+    uint8_t* const orow = mr_smem;
+    uint8_t* const span = mr_smem + RB * OW * 3;
+    __shared__ short cx_s[OW], cx_a[OW];       // source column, a1 (a0 from the same float, see below)
+    __shared__ short cx_a0[OW];
+    __shared__ int ry0[RB], ry1[RB], rb0[RB], rb1[RB];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x / (OH / RB), band = blockIdx.x - f * (OH / RB);
+    const int dy0 = band * RB;
+    const int my = mask_y[f];
+    uint4* out16 = reinterpret_cast<uint4*>(dst + ((long)f * OH + dy0) * (OW * 3));
+    constexpr int OUT_V = RB * OW * 3 / 16;    // 540 16-byte pieces
+    auto sat_short = [](float v) -> int {
+        int r = __float2int_rn(v);
+        return r < -32768 ? -32768 : (r > 32767 ? 32767 : r);
+    };
+    const double scale_x = (double)W / OW, scale_y = (double)H / OH;
+    // per-row coefficients (every thread computes the band's first / last source row itself: wave-uniform, no barrier needed for them)
+    auto row_coef = [&](int dy, int& y0, int& y1, int& b0, int& b1) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = (int)floorf(fy);
+        fy -= sy;
+        b0 = sat_short((1.f - fy) * 2048.f);
+        b1 = sat_short(fy * 2048.f);
+        y0 = sy < 0 ? 0 : (sy < H ? sy : H - 1);
+        y1 = sy + 1 < 0 ? 0 : (sy + 1 < H ? sy + 1 : H - 1);
+    };
+    int ylo, yhi, t0, t1, t2;
+    row_coef(dy0, ylo, t0, t1, t2);
+    row_coef(dy0 + RB - 1, t0, yhi, t1, t2);
+    // rows the band READS: those below the mask (face found) or all of them (face None: the blank rows are cut AFTER the resize)
+    const int row0 = my >= 0 ? (my + 1 < H ? my + 1 : H) : 0;
+    const int rlo = ylo > row0 ? ylo : row0;
+    const uint8_t* fr = src + (long)f * H * W * 3;
+    bool bad = false;
+    if (offs) {
+        const long long o = offs[f];
+        bad = o < 0 || o + (long long)(H - row0) * W * 3 > src_bytes;
+        fr = src + o - (long long)row0 * W * 3;
+    }
+    const bool none = bad || rlo > yhi || (my < 0 && dy0 + RB - 1 <= 110);      // nothing of the source reaches this band
+    if (none) {
+        for (int i = tid; i < OUT_V; i += 256) out16[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    // ---- stage the span [rlo, yhi] of the frame
+    const uint8_t* p_lo = fr + (long)rlo * W * 3;
+    const long nbytes = (long)(yhi - rlo + 1) * W * 3;
+    const int shift = (int)((uintptr_t)p_lo & 3);
+    const uint8_t* p_al = p_lo - shift;                        // >= the allocation's start: allocations are at least 4-byte aligned
+    const long nfull = (shift + nbytes) >> 2;                  // whole dwords inside [p_al, p_lo + nbytes)
+    for (long i = tid; i < nfull; i += 256) reinterpret_cast<uint32_t*>(span)[i] = reinterpret_cast<const uint32_t*>(p_al)[i];
+    for (long i = nfull * 4 + tid; i < shift + nbytes; i += 256) span[i] = p_al[i];
+    for (int dx = tid; dx < OW; dx += 256) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx + 1 >= W) { fx = 0.f; sx = W - 1; }
+        cx_s[dx] = (short)sx;
+        cx_a0[dx] = (short)sat_short((1.f - fx) * 2048.f);
+        cx_a[dx] = (short)sat_short(fx * 2048.f);
+    }
+    if (tid < RB) row_coef(dy0 + tid, ry0[tid], ry1[tid], rb0[tid], rb1[tid]);
+    __syncthreads();
+    const int rowb = W * 3;
+    for (int i = tid; i < RB * OW; i += 256) {
+        const int r = i / OW, dx = i - r * OW;
+        uint8_t* o = orow + i * 3;
+        if (my < 0 && dy0 + r <= 110) {                       // face None: rows 0..110 of the RESIZED frame
+            o[0] = o[1] = o[2] = 0;
+            continue;
+        }
+        const int y0 = ry0[r], y1 = ry1[r], b0 = rb0[r], b1 = rb1[r];
+        const int sx = cx_s[dx], a0 = cx_a0[dx], a1 = cx_a[dx];
+        const int x1 = sx + 1 < W ? sx + 1 : W - 1;
+        const bool z0 = my >= 0 && y0 <= my, z1 = my >= 0 && y1 <= my;
+        const uint8_t* q0 = span + shift + (long)(y0 - rlo) * rowb;
+        const uint8_t* q1 = span + shift + (long)(y1 - rlo) * rowb;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int p00 = z0 ? 0 : q0[sx * 3 + c], p01 = z0 ? 0 : q0[x1 * 3 + c];
+            const int p10 = z1 ? 0 : q1[sx * 3 + c], p11 = z1 ? 0 : q1[x1 * 3 + c];
+            const int S0 = p00 * a0 + p01 * a1, S1 = p10 * a0 + p11 * a1;
+            const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < OUT_V; i += 256) out16[i] = reinterpret_cast<const uint4*>(orow)[i];
+}
+
+hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int* mask_y_dev, uint8_t* dst, hipStream_t s,
+                              const long long* offs, long long src_bytes) {
     const long n = (long)T * 270 * 480;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, T, H, W, mask_y_dev, dst);
+    // source rows a band of MR_RB output rows can touch: (MR_RB - 1) * H / 270 + 3
+    const long span_rows = (long)(MR_RB - 1) * H / 270 + 3;
+    static const bool generic = getenv("JG_MASK_RESIZE_GENERIC") != nullptr;       // A/B and test switch
+    if (span_rows * W * 3 + 4 <= MR_SPAN_MAX && W <= 32767 && !generic) {
+        const size_t lds = (size_t)MR_RB * 480 * 3 + (((size_t)span_rows * W * 3 + 4 + 15) & ~(size_t)15);
+        hipLaunchKernelGGL(mask_resize_band_kernel, dim3((unsigned)(T * (270 / MR_RB))), dim3(256), lds, s, src, T, H, W, mask_y_dev, dst, offs, src_bytes);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(mask_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, T, H, W, mask_y_dev, dst, offs, src_bytes);
     return hipGetLastError();
 }
 
@@ -710,13 +837,17 @@ hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int
 // The reference blanks rows 0 .. y2+15 of every crop (inference_embs.py:264-270): ~40 % of the bytes of a batch are zeros the
 // engine then skips.  A producer ships only the rows BELOW each frame's mask, packed back to back; this kernel rebuilds the
 // dense (frames, 270, 480, 3) batch: frame f's rows >= row0[f] come from packed + offs[f], the rows above are zero.
+// Bad metadata (row0 outside 0..270, an offset that is negative, not a multiple of 16, or whose rows end beyond packed_bytes) makes
+// the frame come out all zero instead of reading out of bounds / misaligned (packed_bytes < 0: unknown size, offsets are trusted).
 __global__ __launch_bounds__(256) void unpack_masked_kernel(const uint8_t* __restrict__ packed, const int* __restrict__ row0,
-                                                            const long long* __restrict__ offs, uint8_t* __restrict__ dst) {
+                                                            const long long* __restrict__ offs, uint8_t* __restrict__ dst, long long packed_bytes) {
     constexpr int ROW_B = 480 * 3, ROW_V = ROW_B / 16, ROWS = 30;          // 90 16-byte pieces per row, 30 rows per block (9 blocks per frame)
     const int f = blockIdx.x;
     const int r_begin = blockIdx.y * ROWS;
-    const int r0 = row0[f];
-    const uint8_t* src = packed + offs[f];
+    int r0 = row0[f];
+    const long long of = offs[f];
+    if (r0 < 0 || r0 > 270 || of < 0 || (of & 15) || (packed_bytes >= 0 && of + (long long)(270 - r0) * ROW_B > packed_bytes)) r0 = 270;
+    const uint8_t* src = packed + of;
     uint8_t* out = dst + (size_t)f * (270 * ROW_B);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     for (int i = threadIdx.x; i < ROWS * ROW_V; i += 256) {
@@ -727,9 +858,10 @@ __global__ __launch_bounds__(256) void unpack_masked_kernel(const uint8_t* __res
     }
 }
 
-hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s) {
+hipError_t launch_unpack_masked(const uint8_t* packed, const int* row0, const long long* offs, int n_frames, uint8_t* dst, hipStream_t s,
+                                long long packed_bytes) {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(unpack_masked_kernel, dim3((unsigned)n_frames, 9), dim3(256), 0, s, packed, row0, offs, dst);
+    hipLaunchKernelGGL(unpack_masked_kernel, dim3((unsigned)n_frames, 9), dim3(256), 0, s, packed, row0, offs, dst, packed_bytes);
     return hipGetLastError();
 }
 

@@ -140,6 +140,50 @@ class _MaskedPacker:
         self.n += 1
 
 
+class _SourcePacker:
+    """Host side of the source-resolution upload: decoder-resolution frames (T,H,W,3) with their mask rows (mask_y = y2+15 per frame,
+    -1 = no face; inference_embs.py:255-270), only the rows BELOW each frame's mask packed back to back in a pinned buffer --
+    what jg_mask_resize_packed consumes."""
+
+    def __init__(self, batch, T, H, W, pinned=True):
+        self.batch, self.T, self.H, self.W = batch, T, int(H), int(W)
+        self.row_bytes = self.W * 3
+        pin = (lambda t: t.pin_memory()) if pinned else (lambda t: t)
+        self.buf = pin(torch.empty((batch * T * self.H * self.row_bytes,), dtype=torch.uint8))
+        self.mask_y = pin(torch.zeros((batch * T,), dtype=torch.int32))
+        self.offs = pin(torch.zeros((batch * T,), dtype=torch.int64))
+        self.reset()
+
+    def reset(self):
+        self.n, self.used = 0, 0
+
+    def add(self, clip, mask_y):
+        """clip (T,H,W,3) uint8 source frames (NOT masked: the rows 0..mask_y are simply not shipped); mask_y int or (T,) ints."""
+        clip = np.asarray(clip)
+        if clip.shape != (self.T, self.H, self.W, 3) or clip.dtype != np.uint8:
+            raise ValueError(f"clip must be uint8 ({self.T},{self.H},{self.W},3), got {clip.dtype} {clip.shape}")
+        if self.n >= self.batch:
+            raise ValueError("batch is full")
+        my = np.broadcast_to(np.asarray(mask_y, np.int64), (self.T,))
+        if my.min() < -1:
+            raise ValueError("mask_y must be >= -1 (-1: no face found)")
+        r0 = np.clip(my + 1, 0, self.H)
+        f0 = self.n * self.T
+        kept = (self.H - r0) * self.row_bytes
+        offs = self.used + np.concatenate(([0], np.cumsum(kept)[:-1]))
+        self.mask_y.numpy()[f0:f0 + self.T] = my
+        self.offs.numpy()[f0:f0 + self.T] = offs
+        dst = self.buf.numpy()
+        if (r0 == r0[0]).all():
+            n = int(kept[0])
+            dst[self.used:self.used + self.T * n].reshape(self.T, n)[:] = clip[:, int(r0[0]):].reshape(self.T, n)
+        else:
+            for t in range(self.T):
+                dst[offs[t]:offs[t] + kept[t]] = clip[t, int(r0[t]):].reshape(-1)
+        self.used += int(kept.sum())
+        self.n += 1
+
+
 class GestureStreamer:
     """Streams host-resident clips through ``jg_extract_gesture`` with the uploads hidden behind the compute.
 
@@ -154,16 +198,29 @@ class GestureStreamer:
     ``run_filled`` with a packer) and ``jg_unpack_masked`` rebuilds the dense batch on the device, on the upload stream.
     Bit-identical to uploading the blanked crops whole.
 
+    ``source_hw=(H, W)`` ships the DECODER's frames: the reference resizes its 228x314 / 294x294 crops up to 270x480 on the host
+    (inference_embs.py:255-276), which is up to 1.8x more bytes than the decoder produced.  Clips are (T,H,W,3) uint8 source
+    frames, ``mask_rows`` gives mask_y = y2+15 per frame (-1: no face), only the source rows below the mask cross the link and
+    ``jg_mask_resize_packed`` (mask + cv2-style bilinear resize) builds the 270x480 crops on the device, on the upload stream.
+    Bit-identical to ``load_rgb_masked_frames`` + the resident path.
+
     ``run(clips)``: ``clips`` iterates over (T,270,480,3) uint8 numpy arrays of one common T; yields
     ``(first_clip_index, embeddings (n,T,512) float32 numpy)`` per batch, in order.
     (The reference's loop does this synchronously per clip: inference_embs.py:476-522,629-637.)
     """
 
-    def __init__(self, engine, batch=32, frames=150, masked=False):
-        self.eng, self.batch, self.T, self.masked = engine, int(batch), int(frames), bool(masked)
+    def __init__(self, engine, batch=32, frames=150, masked=False, source_hw=None):
+        self.eng, self.batch, self.T, self.masked = engine, int(batch), int(frames), bool(masked) or source_hw is not None
+        self.source_hw = None if source_hw is None else (int(source_hw[0]), int(source_hw[1]))
         dev = engine.device
         shape = (self.batch, self.T, 270, 480, 3)
-        if self.masked:
+        if self.source_hw is not None:
+            H, W = self.source_hw
+            self.packer = [_SourcePacker(self.batch, self.T, H, W) for _ in range(2)]
+            self.d_packed = [torch.empty((self.batch * self.T * H * W * 3,), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.d_row0 = [torch.empty((self.batch * self.T,), dtype=torch.int32, device=dev) for _ in range(2)]      # mask_y here
+            self.d_offs = [torch.empty((self.batch * self.T,), dtype=torch.int64, device=dev) for _ in range(2)]
+        elif self.masked:
             self.packer = [_MaskedPacker(self.batch, self.T) for _ in range(2)]
             self.d_packed = [torch.empty((self.batch * self.T * FRAME_BYTES,), dtype=torch.uint8, device=dev) for _ in range(2)]
             self.d_row0 = [torch.empty((self.batch * self.T,), dtype=torch.int32, device=dev) for _ in range(2)]
@@ -186,8 +243,9 @@ class GestureStreamer:
         if self.masked:
             pk = self.packer[slot]
             pk.reset()
+            none = -1 if self.source_hw is not None else 0          # no mask given: the whole frame is shipped
             for clip in it:
-                pk.add(clip, 0 if rows_it is None else next(rows_it))
+                pk.add(clip, none if rows_it is None else next(rows_it))
                 if pk.n == self.batch:
                     break
             return pk.n
@@ -204,7 +262,8 @@ class GestureStreamer:
 
     def run(self, clips, mask_rows=None):
         """clips: iterable of (T,270,480,3) uint8 arrays (copied into the pinned staging buffers here).  masked streamer:
-        mask_rows iterates alongside and gives each clip's first unmasked row (int, or (T,) ints per frame); None = 0."""
+        mask_rows iterates alongside and gives each clip's first unmasked row (int, or (T,) ints per frame); None = 0.
+        source_hw streamer: clips are (T,H,W,3) source frames and mask_rows gives mask_y = y2+15 (-1: no face; None = -1)."""
         it = iter(clips)
         rows_it = None if mask_rows is None else iter(mask_rows)
         if rows_it is not None and not self.masked:
@@ -214,13 +273,27 @@ class GestureStreamer:
     def _upload(self, slot, n):
         """H2D of batch `slot` on the copy stream (+ the unpack kernel of the masked mode, also there)."""
         with torch.cuda.stream(self.copy):
-            if self.masked:
+            if self.source_hw is not None:
+                pk = self.packer[slot]
+                F = n * self.T
+                self.d_packed[slot][:pk.used].copy_(pk.buf[:pk.used], non_blocking=True)
+                self.d_row0[slot][:F].copy_(pk.mask_y[:F], non_blocking=True)
+                self.d_offs[slot][:F].copy_(pk.offs[:F], non_blocking=True)
+                if pk.used == 0:                     # every frame masked completely: nothing crossed the link
+                    self.d_in[slot][:n].zero_()
+                else:
+                    self.eng.mask_resize_packed(self.d_packed[slot][:pk.used], self.d_offs[slot][:F], self.d_row0[slot][:F], self.source_hw[0],
+                                                self.source_hw[1], self.d_in[slot][:n])
+            elif self.masked:
                 pk = self.packer[slot]
                 F = n * self.T
                 self.d_packed[slot][:pk.used].copy_(pk.buf[:pk.used], non_blocking=True)
                 self.d_row0[slot][:F].copy_(pk.row0[:F], non_blocking=True)
                 self.d_offs[slot][:F].copy_(pk.offs[:F], non_blocking=True)
-                self.eng.unpack_masked(self.d_packed[slot], self.d_row0[slot][:F], self.d_offs[slot][:F], self.d_in[slot][:n])
+                if pk.used == 0:
+                    self.d_in[slot][:n].zero_()
+                else:
+                    self.eng.unpack_masked(self.d_packed[slot][:pk.used], self.d_row0[slot][:F], self.d_offs[slot][:F], self.d_in[slot][:n])
             else:
                 self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
             self.uploaded[slot].record(self.copy)

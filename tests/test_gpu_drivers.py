@@ -135,7 +135,7 @@ def test_gesture_streamer_matches_resident_path():
     np.testing.assert_array_equal(np.concatenate([e for _, e in got4]), refj)
 
 
-@pytest.mark.parametrize("H,W", [(270, 480), (360, 640), (720, 1280), (301, 533), (135, 240)])
+@pytest.mark.parametrize("H,W", [(270, 480), (360, 640), (720, 1280), (301, 533), (135, 240), (228, 314), (294, 294)])
 def test_mask_resize_matches_oracle(H, W):
     """face-mask + cv2-style bilinear resize kernel == the numpy restatement, bit for bit
     (up- and down-scaling, identity size, odd sizes; face / no-face / mask-beyond-frame rows)."""

@@ -122,6 +122,63 @@ def test_unpack_masked_rebuilds_the_dense_batch():
     dst = torch.full((F, 270, 480, 3), 7, dtype=torch.uint8, device="cuda")
     eng.unpack_masked(torch.from_numpy(packed).cuda(), torch.from_numpy(rows).cuda(), torch.from_numpy(np.array(offs, np.int64)).cuda(), dst)
     assert np.array_equal(dst.cpu().numpy(), dense)
+    # bad metadata: row0 outside 0..270, a misaligned / negative offset, rows running past the end of `packed` -- such a
+    # frame comes out all zero, nothing is read out of bounds; the good frames are untouched
+    bad_rows, bad_offs = rows.copy(), np.array(offs, np.int64)
+    bad_rows[1] = 300
+    bad_rows[2] = -5
+    bad_offs[3] = offs[3] + 4                     # not a multiple of 16
+    bad_offs[5] = packed.size - 1440 * 10 - (packed.size - 1440 * 10) % 16          # 135 kept rows do not fit behind it
+    bad_offs[6] = -16
+    dst.fill_(7)
+    eng.unpack_masked(torch.from_numpy(packed).cuda(), torch.from_numpy(bad_rows).cuda(), torch.from_numpy(bad_offs).cuda(), dst)
+    got = dst.cpu().numpy()
+    for f in (1, 2, 3, 5, 6):
+        assert got[f].max() == 0, f
+    for f in (0, 4):
+        assert np.array_equal(got[f], dense[f]), f
+
+
+@pytest.mark.parametrize("H,W", [(228, 314), (294, 294), (360, 640)])
+def test_source_resolution_streamer_is_bit_identical(H, W):
+    """GestureStreamer(source_hw=(H, W)) ships the decoder's frames (inference_embs.py:255-276 resizes 228x314 /
+    294x294 crops up to 270x480 on the host) -- only the source rows below each frame's mask -- and jg_mask_resize_packed builds the
+    crops on the upload stream.  Embeddings must equal load_rgb_masked_frames' crops (jg_mask_resize of the full frames, itself
+    bit-exact against the oracle's cv2 restatement) through the resident path, bit for bit; the packed kernel alone equals the
+    unpacked one, incl. no-face frames (-1), a fully masked frame and mask_y beyond the frame."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.extract import GestureStreamer, _SourcePacker
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    eng = Engine.get("cuda:0")
+    GestSync(engine=eng).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=eng).load_state_dict(synth.jegal_state_dict())
+    rng = np.random.default_rng(H + W)
+    T, n = 8, 5
+    src = rng.integers(0, 256, (n, T, H, W, 3), dtype=np.uint8)
+    my = rng.integers(H // 4, H // 2, (n, T)).astype(np.int64)
+    my[0, 1], my[1, 2], my[2, 3], my[3, 0] = -1, H - 1, H + 40, 0
+    # kernel alone
+    pk = _SourcePacker(n, T, H, W, pinned=False)
+    for b in range(n):
+        pk.add(src[b], my[b])
+    dst = torch.empty((n * T, 270, 480, 3), dtype=torch.uint8, device="cuda")
+    eng.mask_resize_packed(pk.buf[:pk.used].cuda(), pk.offs.cuda(), pk.mask_y.cuda(), H, W, dst)
+    ref_crops = torch.stack([eng.mask_resize(torch.from_numpy(src[b]), my[b].astype(np.int32)) for b in range(n)])
+    assert torch.equal(dst.reshape(n, T, 270, 480, 3), ref_crops)
+    np.testing.assert_array_equal(ref_crops[1].cpu().numpy(), O.mask_resize_frames(src[1], list(my[1])))
+    assert pk.used < src.size * 0.8                                     # the masked rows did not cross the link
+    # through the streamer (batches of 2, ragged last batch)
+    ref = np.concatenate([eng.extract_gesture(ref_crops[i:i + 2]).cpu().numpy() for i in range(0, n, 2)])
+    st = GestureStreamer(eng, batch=2, frames=T, source_hw=(H, W))
+    got = list(st.run(iter(src), mask_rows=list(my)))
+    assert [f for f, _ in got] == [0, 2, 4]
+    np.testing.assert_array_equal(np.concatenate([e for _, e in got]), ref)
+    # a frame whose rows would run past the packed buffer is written as zeros, not read
+    bad = pk.offs.clone()
+    bad[7] = pk.used - 10
+    eng.mask_resize_packed(pk.buf[:pk.used].cuda(), bad.cuda(), pk.mask_y.cuda(), H, W, dst)
+    assert int(dst[7].max()) == 0 and torch.equal(dst[6], ref_crops.reshape(-1, 270, 480, 3)[6])
 
 
 @pytest.mark.parametrize("nclip,T", [(1, 8), (3, 8), (3, 10), (2, 8), (1, 5)])

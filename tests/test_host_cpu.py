@@ -41,6 +41,10 @@ def test_hot_kernels_do_not_spill():
     assert len(hot) >= 10
     bad = {k: v for k, v in hot.items() if v["spill"] != 0 or v["vgpr"] > 256}
     assert not bad, bad
+    # and no kernel of the library at all may spill VGPRs: round 4 found audio_conv0_kernel at 512 VGPRs + 316 spills after a
+    # three-line change (3.8 ms instead of 0.1 ms per call) -- invisible to every parity test
+    spilled = {k: v["spill"] for k, v in res.items() if v["spill"] != 0}
+    assert not spilled, spilled
 
 
 def test_engine_fails_loudly_without_gpu():
@@ -332,3 +336,28 @@ def test_two_rank_gloo_sharded_spotting_and_asd(tmp_path):
             raise AssertionError(text)
     for rc, out in outs:
         assert " ok" in out
+
+
+def test_source_packer_layout():
+    """Host side of the source-resolution upload (jegal_amd.extract._SourcePacker): per frame the source rows mask_y+1 .. H-1 back to
+    back, mask_y and byte offsets per frame -- what jg_mask_resize_packed consumes (include/jegal_hip.h)."""
+    from jegal_amd.extract import _SourcePacker
+    T, H, W = 3, 228, 314
+    rng = np.random.default_rng(1)
+    clips = rng.integers(0, 256, (2, T, H, W, 3), dtype=np.uint8)
+    pk = _SourcePacker(2, T, H, W, pinned=False)
+    pk.add(clips[0], 90)
+    pk.add(clips[1], np.array([-1, H - 1, H + 30]))                      # whole frame / nothing / nothing (mask beyond the frame)
+    my, offs, buf = pk.mask_y.numpy(), pk.offs.numpy(), pk.buf.numpy()
+    assert my.tolist() == [90, 90, 90, -1, H - 1, H + 30]
+    row0 = np.clip(my.astype(np.int64) + 1, 0, H)
+    kept = (H - row0) * W * 3
+    assert offs.tolist() == np.concatenate(([0], np.cumsum(kept)[:-1])).tolist() and pk.used == int(kept.sum())
+    for f in range(2 * T):
+        b, t = divmod(f, T)
+        assert np.array_equal(buf[offs[f]:offs[f] + kept[f]], clips[b, t, row0[f]:].reshape(-1))
+    with pytest.raises(ValueError):
+        pk.add(clips[0], 90)
+    pk.reset()
+    with pytest.raises(ValueError):
+        pk.add(clips[0], -2)
