@@ -48,6 +48,7 @@ _SIGS = {
     "jg_mask_resize_packed": [_P, _P, ctypes.c_int64, _P, _I, _I, _I, _P, _P],
     "jg_jegal_text": [_P, _P, _P, _I, _I, _P],
     "jg_xlmr_encode": [_P, _P, _P, _I, _I, _P],
+    "jg_calibrate_xlmr": [_P, _P, _P, _I, _I],
     "jg_word_pool": [_P, _P, _I, _P, _I, _P, _I, _I],
     "jg_fuse_content": [_P, _P, _I, _P],
     "jg_l2norm": [_P, _P, _P, _I, _I],
@@ -396,6 +397,21 @@ class Engine:
         out = torch.empty((B, L, 768), dtype=torch.float32, device=self.device)
         self._ck(self.lib.jg_xlmr_encode(self.h, _ptr(ids), _ptr(m), B, L, _ptr(out)))
         return out
+
+    def calibrate_xlmr(self, input_ids=None, attention_mask=None):
+        """Precision mode 3: switch the XLM-RoBERTa Linears from hi+lo to bias-corrected single fp16, calibrated on these token ids
+        ((B,L) ints; None = built-in uniform-random ids, validated on seeded test weights only)."""
+        self._bind_stream()
+        if input_ids is None:
+            self._ck(self.lib.jg_calibrate_xlmr(self.h, None, None, 0, 0))
+            return
+        ids = self._i32(input_ids)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be (B, L)")
+        m = None if attention_mask is None else self._i32(attention_mask)
+        if m is not None and tuple(m.shape) != tuple(ids.shape):
+            raise ValueError("attention_mask must have the shape of input_ids")
+        self._ck(self.lib.jg_calibrate_xlmr(self.h, _ptr(ids), _ptr(m), ids.shape[0], ids.shape[1]))
 
     def word_pool(self, seq, segments, dst, dst_col):
         """seq (rows,D) fp32; segments int (n,3) = (start,end_excl,dst_row); dst (rows_out, ld) fp32."""

@@ -53,6 +53,7 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     // the weight-rounding error, (w - fp16(w)) . E[x], is folded into `bias` after a calibration pass that runs
     // with hi+lo weights (wl_calib) and records the per-channel mean of this layer's input (mu).
     bool bc = false;
+    bool bc_pending = false;    // LK_XLMR: no calibration yet -- the run-time GEMM keeps using hi+lo (wl == wl_calib); jg_calibrate_xlmr clears it
     f16* wl_calib = nullptr;
     float* mu = nullptr;        // device [K]: column sums of the A operand seen during calibration
     long mu_rows = 0;
@@ -276,12 +277,16 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     if (split) RET(upload(h, lo, &L->wl));
     RET(upload(h, bias, &L->bias));
     L->bc = bc;
+    L->bc_pending = false;
     if (bc) {
         RET(upload(h, lo, &L->wl_calib));
         RET(walloc<float>(h, (size_t)K, &L->mu));
         L->w32 = w;
         L->b32 = bias;
         h->bc_layers.push_back(L);
+        // XLM-RoBERTa: calibration-free hi+lo until jg_calibrate_xlmr has seen the caller's token ids (the released checkpoint has
+        // strong outlier activation dimensions; bias corrections recorded on made-up ids were never validated for it)
+        if (kind == LK_XLMR) { L->wl = L->wl_calib; L->bc_pending = true; }
     }
     return JG_OK;
 }
@@ -906,6 +911,7 @@ int apply_bias_corrections(jg_handle* h, int models) {
         }
         HIPCHK(h, hipMemcpy(L->bias, nb.data(), sizeof(float) * L->N, hipMemcpyHostToDevice));
         L->mu_rows = 0;
+        if (L->bc_pending) { L->wl = nullptr; L->bc_pending = false; }      // calibrated: single fp16 + corrected bias from here on
     }
     h->gs_qpe_valid = false;          // the projected positional rows carry layer 0's qkv bias
     return JG_OK;
@@ -913,24 +919,31 @@ int apply_bias_corrections(jg_handle* h, int models) {
 
 int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out);
 
-// Bias corrections of the XLM-RoBERTa layers: one pass over built-in token ids (uniform over the vocabulary, no padding) with
-// hi+lo weights records every Linear's input means.  (E[x] behind a LayerNorm is mostly its beta and the mean of the position /
-// type embeddings: it depends little on WHICH tokens are drawn.)
-int calibrate_xlmr(jg_handle* h) {
-    if (!h->xl_ready) return JG_OK;
-    const int B = 8, L = 64;
-    std::vector<int32_t> ids((size_t)B * L);
-    uint32_t x = 0xC0FFEE11u;
-    for (auto& v : ids) {
-        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-        v = 3 + (int32_t)(x % (uint32_t)(h->xl_vocab > 3 ? h->xl_vocab - 3 : 1));
-    }
-    for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 0; ids[(size_t)b * L + L - 1] = 2; }       // <s> ... </s>
+// Bias corrections of the XLM-RoBERTa layers (JG_PREC_FP16_BC): one pass with hi+lo weights over token ids records every Linear's
+// input means; the run-time GEMMs then switch from hi+lo to single fp16 + corrected bias.  ids_dev / mask_dev (B, L): the CALLER's
+// tokens (device); ids_dev == nullptr: built-in ids, uniform over the vocabulary, no padding (E[x] behind a LayerNorm is mostly
+// its beta and the mean of the position / type embeddings -- true for the seeded test weights, unvalidated for the released
+// checkpoint, which is why nothing calls this implicitly).
+int calibrate_xlmr(jg_handle* h, const int32_t* ids_dev, const int32_t* mask_dev, int B, int L) {
+    if (!h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "XLM-RoBERTa weights not finalized");
     int32_t* dids = nullptr;
+    if (!ids_dev) {
+        B = 8; L = 64;
+        std::vector<int32_t> ids((size_t)B * L);
+        uint32_t x = 0xC0FFEE11u;
+        for (auto& v : ids) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            v = 3 + (int32_t)(x % (uint32_t)(h->xl_vocab > 3 ? h->xl_vocab - 3 : 1));
+        }
+        for (int b = 0; b < B; ++b) { ids[(size_t)b * L] = 0; ids[(size_t)b * L + L - 1] = 2; }       // <s> ... </s>
+        HIPCHK(h, hipMalloc(&dids, ids.size() * sizeof(int32_t)));
+        if (hipMemcpy(dids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dids); JG_FAIL(h, JG_ERR_HIP, "hipMemcpy failed"); }
+        ids_dev = dids;
+        mask_dev = nullptr;
+    }
     float* out = nullptr;
-    HIPCHK(h, hipMalloc(&dids, ids.size() * sizeof(int32_t)));
-    if (hipMalloc(&out, (size_t)B * L * 768 * sizeof(float)) != hipSuccess) { (void)hipFree(dids); JG_FAIL(h, JG_ERR_HIP, "hipMalloc failed"); }
-    int rc = hipMemcpy(dids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess ? JG_OK : JG_ERR_HIP;
+    if (hipMalloc(&out, (size_t)B * L * 768 * sizeof(float)) != hipSuccess) { if (dids) (void)hipFree(dids); JG_FAIL(h, JG_ERR_HIP, "hipMalloc failed"); }
+    int rc = JG_OK;
     for (Lin* Ly : h->bc_layers) {
         if (Ly->model != 3) continue;
         if (hipMemsetAsync(Ly->mu, 0, sizeof(float) * Ly->K, h->stream) != hipSuccess) rc = JG_ERR_HIP;
@@ -939,12 +952,12 @@ int calibrate_xlmr(jg_handle* h) {
     if (rc == JG_OK) {
         h->calib = true;
         h->ws.reset();
-        rc = xlmr_encode_impl(h, dids, nullptr, B, L, out);
+        rc = xlmr_encode_impl(h, ids_dev, mask_dev, B, L, out);
         h->calib = false;
     }
     if (rc == JG_OK) rc = apply_bias_corrections(h, 4);
     (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(dids);
+    if (dids) (void)hipFree(dids);
     (void)hipFree(out);
     return rc;
 }
@@ -1382,7 +1395,7 @@ int jg_finalize_weights(jg_handle* h, int which) {
     // Built-in calibration only for the gesture models finalized by THIS call (XLM-R has no bias-corrected layers): the bias
     // corrections of the other model -- possibly from jg_calibrate_gesture on real clips -- are left as they are.
     if (h->precision == JG_PREC_FP16_BC && (which & 3)) RET(calibrate_impl(h, nullptr, JG_U8, 0, 0, which & 3));
-    if (h->precision == JG_PREC_FP16_BC && (which & 4)) RET(calibrate_xlmr(h));
+    // XLM-RoBERTa is NOT calibrated implicitly: its Linears run hi+lo (calibration-free) until jg_calibrate_xlmr is called
     return JG_OK;
 }
 
@@ -1397,6 +1410,13 @@ int jg_calibrate_gesture(jg_handle* h, const void* frames, int dtype, int B, int
     if (h->precision != JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC");
     if (frames && (B <= 0 || T <= 0 || (dtype != JG_U8 && dtype != JG_F32))) JG_FAIL(h, JG_ERR_ARG, "bad calibration batch");
     return calibrate_impl(h, frames, dtype, B, T, 3);
+}
+
+int jg_calibrate_xlmr(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L) {
+    ENTER(h);
+    if (h->precision != JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC");
+    if (input_ids && (B <= 0 || L <= 0)) JG_FAIL(h, JG_ERR_ARG, "bad calibration batch");
+    return calibrate_xlmr(h, input_ids, attention_mask, B, L);
 }
 
 int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, float* out) {

@@ -84,10 +84,12 @@ def spotting_counts(pred, score, word_boundaries, target_idx, thresh=0.5, frame_
     return correct, len(word_boundaries)
 
 
-def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, frame_thresh=9, engine=None):
+def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, frame_thresh=9, engine=None, offsets=None):
     """get_spotting_acc (evaluate_spotting.py:59-90).  ``targets`` are word indices (the reference
     looks the target boundary up in the clip's list, :70) or [word,start,end] boundaries.
-    Sharded when torch.distributed is initialised: every rank passes ITS block of clips, the two counters are all-reduced."""
+    Sharded when torch.distributed is initialised: every rank passes ITS block of clips, the two counters are all-reduced.
+    gestures / contents: lists of per-clip (T_i,512) / (W_i,512) arrays as the evaluators load them from the .pkl files, or -- with
+    ``offsets=(g_offsets, c_offsets)`` -- the already concatenated (sum T,512) / (sum W,512) tensors (device-resident galleries)."""
     eng = engine or Engine.get()
     wbs = [ast.literal_eval(w) if isinstance(w, str) else w for w in word_boundaries]
     tidx = []
@@ -97,9 +99,13 @@ def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, 
         tidx.append(wb.index(t) if isinstance(t, (list, tuple)) else int(t))
     correct = 0
     if len(wbs):                                  # (a rank may hold no clip when there are fewer clips than ranks)
-        g = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in gestures], 0))
-        c = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in contents], 0))
-        pred, score = eng.spot(g, c, _offsets(gestures), _offsets(contents), tidx)
+        if offsets is not None:
+            g, c, (goff, coff) = gestures, contents, offsets
+        else:
+            g = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in gestures], 0))
+            c = torch.as_tensor(np.concatenate([np.asarray(x, np.float32) for x in contents], 0))
+            goff, coff = _offsets(gestures), _offsets(contents)
+        pred, score = eng.spot(g, c, goff, coff, tidx)
         correct, _ = spotting_counts(pred.cpu().numpy(), score.cpu().numpy(), wbs, tidx, thresh, frame_thresh)
     correct, total = reduce_counts([correct, len(wbs)], eng.device)
     return 100.0 * correct / total

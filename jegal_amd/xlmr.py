@@ -37,6 +37,13 @@ class XLMRoberta:
         self.engine.finalize(4)
         return self
 
+    def calibrate(self, input_ids=None, attention_mask=None):
+        """Engine precision mode 3 (the default): the Linears run hi+lo fp16 (calibration-free) until this is called; then single
+        fp16 with bias corrections recorded on THESE token ids (a few hundred tokens of the text at hand are enough; None = built-in
+        uniform-random ids, validated on seeded test weights only).  ~1.5x faster encoder, same 1e-3 contract on the test weights."""
+        self.engine.calibrate_xlmr(input_ids, attention_mask)
+        return self
+
     def eval(self):
         return self
 

@@ -149,3 +149,46 @@ def test_xlmr_12_layers_matches_transformers_golden(golden_dir):
     print("xlmr 12 layers vs transformers golden: rel-L2 %.3e, max-abs %.3e" % (e, float((out[mk] - ref[mk]).abs().max())))
     eng.close()
     assert e < TOL
+
+
+def test_xlmr_calibration_is_explicit_and_holds_on_other_token_distributions():
+    """in the default precision mode the XLM-R Linears were bias-corrected single fp16, calibrated implicitly on
+    uniform-random ids without padding -- and every check drew its ids from that same distribution.  Now: (1) after
+    load_state_dict the encoder runs hi+lo (calibration-free); (2) calibrate(ids, mask) is explicit; (3) a calibration on UNIFORM
+    unpadded ids is tested on a DIFFERENT distribution -- heavily skewed ids (90 % of the tokens from 20 ids), ragged padding --
+    and (4) a calibration on the skewed padded ids themselves; all within 1e-3 of the fp32 restatement, errors printed."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.xlmr import XLMRoberta
+    eng = Engine(0)
+    sd = synth.xlmr_state_dict()
+    m = XLMRoberta(engine=eng).load_state_dict({"roberta." + k: v for k, v in sd.items()})
+    rng = np.random.default_rng(99)
+    B, L = 6, 48
+    ids = np.where(rng.random((B, L)) < 0.9, rng.integers(3, 23, (B, L)), rng.integers(3, 1000, (B, L))).astype(np.int64)
+    lens = [48, 9, 30, 17, 48, 5]
+    mask = np.zeros((B, L), np.int64)
+    for b, l in enumerate(lens):
+        ids[b, 0], ids[b, l - 1] = 0, 2
+        ids[b, l:] = 1
+        mask[b, :l] = 1
+    with torch.no_grad():
+        ref = O.xlmr_forward(sd, ids, mask)
+    mm = torch.from_numpy(mask).bool()
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    res = {}
+    res["hi+lo (default, uncalibrated)"] = rel(m(ids_d, attention_mask=mask_d).last_hidden_state.cpu()[mm], ref[mm])
+    m.calibrate()                                                       # built-in: uniform ids, no padding
+    res["calibrated on uniform unpadded ids"] = rel(m(ids_d, attention_mask=mask_d).last_hidden_state.cpu()[mm], ref[mm])
+    m.calibrate(ids_d, mask_d)                                          # the caller's own tokens
+    res["calibrated on these ids"] = rel(m(ids_d, attention_mask=mask_d).last_hidden_state.cpu()[mm], ref[mm])
+    print("\nXLM-R, skewed + padded ids vs the fp32 restatement:", {k: f"{v:.2e}" for k, v in res.items()})
+    for k, v in res.items():
+        assert v < TOL, (k, v)
+    eng.close()
+    # calibration outside mode 3 is an error, not a silent no-op
+    from jegal_amd._lib import JegalError, PREC_FP16_W2
+    e2 = Engine(0, precision=PREC_FP16_W2)
+    m2 = XLMRoberta(engine=e2).load_state_dict({"roberta." + k: v for k, v in sd.items()})
+    with pytest.raises(JegalError):
+        m2.calibrate()
+    e2.close()

@@ -14,15 +14,24 @@ ids, mask = synth.xlmr_inputs(1, B, L)
 eng = Engine(0)
 m = XLMRoberta(engine=eng).load_state_dict(sd)
 ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
-for _ in range(3):
-    out = m(ids_d, attention_mask=mask_d).last_hidden_state
-torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 20
-for _ in range(n):
-    out = m(ids_d, attention_mask=mask_d).last_hidden_state
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 flop = B * L * 12 * 2 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + B * 12 * 4 * L * L * 768
-print("engine: B=%d L=%d 12 layers: %.3f ms per batch, %.0f tokens/s, %.1f TFLOP/s" % (B, L, dt * 1e3, B * L / dt, flop / dt / 1e12))
+n = 20
+
+
+def run(tag):
+    global out
+    for _ in range(3):
+        out = m(ids_d, attention_mask=mask_d).last_hidden_state
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        out = m(ids_d, attention_mask=mask_d).last_hidden_state
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print("engine (%s): B=%d L=%d 12 layers: %.3f ms per batch, %.0f tokens/s, %.1f TFLOP/s" % (tag, B, L, dt * 1e3, B * L / dt, flop / dt / 1e12))
+
+
+run("hi+lo weights: the default until calibrate()")
+m.calibrate(ids_d[:8], mask_d[:8])
+run("bias-corrected single fp16, calibrated on 8 of these sequences")
 try:
     from transformers import XLMRobertaConfig, XLMRobertaModel
     cfg = XLMRobertaConfig(vocab_size=sd["embeddings.word_embeddings.weight"].shape[0], hidden_size=768, num_hidden_layers=12,
