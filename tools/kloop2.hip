@@ -1,0 +1,290 @@
+// Micro-benchmark (round 4): the k loop of the 256x256 LDS-DMA GEMM tile in the regime the path actually runs in -- K = 512,
+// operands L2-resident (weights shared by every workgroup, an activation panel shared by the N tiles of an XCD) -- with the real
+// fragment reads and MFMA schedule but NO epilogue: microseconds per 64-deep k-tile for several staging pipelines.
+// (Round 2's tools/experiments/micro/gemm_kloop.hip ran K = 4096 on private panels, i.e. from HBM at 24 GB/s per CU, where every
+// pipeline looks the same, and at K = 512 its fragment-order epilogue dominated.)
+//   hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/kloop2.hip -o tools/bin/kloop2
+//   V0  two stages of BK = 64, vmcnt(0) + barrier per k-tile, the next k-tile's 8 pieces issued in one burst behind the barrier
+//   V1  the same, pieces spread one per MFMA group (gemm_glds_kernel's SPR instances)
+//   V2  ring of 4 half-stages (BK = 32), one barrier per half-step, counted vmcnt: 2 half-steps stay in flight across the barriers
+//   V3  ring of 4 half-stages, 3 half-steps in flight (the slot being refilled is the one read in the PREVIOUS half-step: needs the
+//       barrier at the top of the half-step to have been passed by everyone -- it has)
+//   V5  V0 with the fragment pipeline carried across the two k-steps of a k-tile (no LDS latency exposed between them)
+// Result (profiles/r4_kloop2.txt): all variants within the run-to-run spread (1.65-1.85 us per k-tile at K = 512, the first
+// launches after an idle gap being the slow ones); neither deeper DMA pipelining nor fragment prefetch across k-steps moves it.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int BM = 256, BN = 256;
+
+// tile -> operand bases: weights W[N][K] shared by all (N tile = tile % n_tiles), activations A: panel (tile / n_tiles) of 256 rows
+template <int V>
+__global__ __launch_bounds__(512) void kloop(const f16* __restrict__ A, const f16* __restrict__ W, float* __restrict__ sink, int M, int N, int K, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave % 2, wn = wave / 2;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n_tiles = N / BN;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int G = gridDim.x;
+    // XCD-aware order as in gemm_glds_kernel: the workgroups of an XCD take consecutive tile ids (N tiles of one panel share an L2)
+    auto tile_of = [&](int round) -> int {
+        const int v0 = round * G;
+        const int b = blockIdx.x, xcd = b % 8, loc = b / 8, q = G / 8;
+        return (v0 + xcd * q + loc) % tiles;
+    };
+    const int rounds = 64;
+    if constexpr (V == 5) {
+        // V0 with the fragment pipeline carried ACROSS the two k-steps of a k-tile: the activation fragments of k-step 1 are prefetched
+        // into the slots k-step 0 frees in its last two groups, and the four weight fragments are reloaded one by one behind the MFMAs
+        // of the last group that read them -- only the barrier still exposes an LDS latency
+        constexpr int XB = BM * 128, STAGE = XB + BN * 128;
+        const int lrow = lane >> 3, pc = lane & 7;
+        const int fsw = (frow >> 1) & 7;
+        const int nk = K / 64;
+        const f16* xs[4]; const f16* ws[4];
+        auto setup = [&](int tile) {
+            const int n0 = (tile % n_tiles) * BN, m0 = (tile / n_tiles) * BM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (wave * 4 + i) * 8 + lrow;
+                const int c = pc ^ ((row >> 1) & 7);
+                xs[i] = A + (long)(m0 + row) * K + c * 8;
+                ws[i] = W + (long)(n0 + row) * K + c * 8;
+            }
+        };
+        auto piece = [&](int p, int kt, int buf) __attribute__((always_inline)) {
+            char* base = smem + buf * STAGE;
+            if (p < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs[p] + kt * 64), (lds_ptr_t)(base + (wave * 4 + p) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws[p - 4] + kt * 64), (lds_ptr_t)(base + XB + (wave * 4 + p - 4) * 1024), 16, 0, 0);
+        };
+        int gk = 0;
+        setup(tile_of(0));
+#pragma unroll
+        for (int p = 0; p < 8; ++p) piece(p, 0, 0);
+        for (int r = 0; r < rounds; ++r) {
+            for (int kt = 0; kt < nk; ++kt, ++gk) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                const bool last = kt + 1 == nk;
+                if (last) setup(tile_of(r + 1));
+                const int nkt = last ? 0 : kt + 1;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) piece(p, nkt, (gk + 1) & 1);
+                const char* sX = smem + (gk & 1) * STAGE;
+                const char* sW = sX + XB;
+                const int ch0 = ((0 * 4 + fq) ^ fsw) << 4, ch1 = ((1 * 4 + fq) ^ fsw) << 4;
+                auto ldx = [&](int j, int ch) -> f16x8 { return *reinterpret_cast<const f16x8*>(sX + (wm * 128 + j * 16 + frow) * 128 + ch); };
+                auto ldw = [&](int i, int ch) -> f16x8 { return *reinterpret_cast<const f16x8*>(sW + (wn * 64 + i * 16 + frow) * 128 + ch); };
+                f16x8 wf[4], xq[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = ldw(i, ch0);
+                xq[0] = ldx(0, ch0);
+                xq[1] = ldx(1, ch0);
+                __builtin_amdgcn_sched_barrier(0);
+                // 16 groups g = kk * 8 + j; group g uses slot g % 3; two groups ahead: g + 2
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int kk = g >> 3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][g & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[g % 3], acc[i][g & 7], 0, 0, 0);
+                        if (g == 7) wf[i] = ldw(i, ch1);                   // k-step 1's weights, behind the last MFMA that read k-step 0's
+                    }
+                    if (g + 2 < 16) xq[(g + 2) % 3] = ldx((g + 2) & 7, (g + 2) >> 3 ? ch1 : ch0);
+                    (void)kk;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else if constexpr (V == 0 || V == 1) {
+        constexpr int XB = BM * 128, STAGE = XB + BN * 128;
+        const int lrow = lane >> 3, pc = lane & 7;
+        const int fsw = (frow >> 1) & 7;
+        const int nk = K / 64;
+        const f16* xs[4]; const f16* ws[4];
+        auto setup = [&](int tile) {
+            const int n0 = (tile % n_tiles) * BN, m0 = (tile / n_tiles) * BM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (wave * 4 + i) * 8 + lrow;
+                const int c = pc ^ ((row >> 1) & 7);
+                xs[i] = A + (long)(m0 + row) * K + c * 8;
+                ws[i] = W + (long)(n0 + row) * K + c * 8;
+            }
+        };
+        auto piece = [&](int p, int kt, int buf) __attribute__((always_inline)) {
+            char* base = smem + buf * STAGE;
+            if (p < 4) __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs[p] + kt * 64), (lds_ptr_t)(base + (wave * 4 + p) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws[p - 4] + kt * 64), (lds_ptr_t)(base + XB + (wave * 4 + p - 4) * 1024), 16, 0, 0);
+        };
+        int gk = 0;                                   // global k-tile counter (stage parity runs across tiles)
+        setup(tile_of(0));
+#pragma unroll
+        for (int p = 0; p < 8; ++p) piece(p, 0, 0);
+        for (int r = 0; r < rounds; ++r) {
+            for (int kt = 0; kt < nk; ++kt, ++gk) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                const bool last = kt + 1 == nk;
+                if (last) setup(tile_of(r + 1));
+                const int nkt = last ? 0 : kt + 1;
+                if (V == 0) {
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) piece(p, nkt, (gk + 1) & 1);
+                }
+                const char* sX = smem + (gk & 1) * STAGE;
+                const char* sW = sX + XB;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int choff = ((kk * 4 + fq) ^ fsw) << 4;
+                    auto ldx = [&](int j) -> f16x8 { return *reinterpret_cast<const f16x8*>(sX + (wm * 128 + j * 16 + frow) * 128 + choff); };
+                    f16x8 wf[4], xq[3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f16x8*>(sW + (wn * 64 + i * 16 + frow) * 128 + choff);
+                    xq[0] = ldx(0);
+                    xq[1] = ldx(1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
+                        if (j + 2 < 8) xq[(j + 2) % 3] = ldx(j + 2);
+                        if (V == 1 && (kk * 8 + j) < 8) piece(kk * 8 + j, nkt, (gk + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- ring of 4 half-stages (BK = 32): rows of 64 B, pieces of 16 rows, swizzle chunk ^= f[(row >> 2) & 3], f = {0,2,3,1}
+        constexpr int NS = 4;
+        constexpr int XB = BM * 64, SLOT = XB + BN * 64;
+        constexpr int DIST = V == 2 ? 2 : 3;             // half-steps in flight behind the one being computed
+        const int lrow = lane >> 2, pc = lane & 3;
+        const int nh = K / 32;
+        const f16* xs[2]; const f16* ws[2];
+        auto setup = [&](int tile) {
+            const int n0 = (tile % n_tiles) * BN, m0 = (tile / n_tiles) * BM;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wave * 2 + i) * 16 + lrow;
+                const int g = (row >> 2) & 3;
+                const int f = g == 0 ? 0 : g == 1 ? 2 : g == 2 ? 3 : 1;
+                const int c = pc ^ f;
+                xs[i] = A + (long)(m0 + row) * K + c * 8;
+                ws[i] = W + (long)(n0 + row) * K + c * 8;
+            }
+        };
+        long ghs = 0;                                   // global half-step counter of the ISSUE side
+        auto stage = [&](int hs, long slot) __attribute__((always_inline)) {
+            char* base = smem + (slot % NS) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs[i] + hs * 32), (lds_ptr_t)(base + (wave * 2 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws[i] + hs * 32), (lds_ptr_t)(base + XB + (wave * 2 + i) * 1024), 16, 0, 0);
+        };
+        const int g = (frow >> 2) & 3;
+        const int ff = g == 0 ? 0 : g == 1 ? 2 : g == 2 ? 3 : 1;
+        const int choff = (fq ^ ff) << 4;
+        // the issue side runs DIST half-steps ahead of the compute side, across tile boundaries (issue position: tile ir, half-step ih)
+        int ir = 0, ih = 0;
+        setup(tile_of(0));
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            stage(ih, ghs);
+            ++ghs;
+            if (++ih == nh) { ih = 0; ++ir; setup(tile_of(ir)); }
+        };
+#pragma unroll
+        for (int d = 0; d < DIST; ++d) issue_next();
+        long chs = 0;
+        for (int r = 0; r < rounds; ++r) {
+            for (int hs = 0; hs < nh; ++hs, ++chs) {
+                if (DIST == 3) wait_vmcnt<8>(); else wait_vmcnt<4>();      // all but the DIST-1 youngest half-steps have landed
+                __builtin_amdgcn_s_barrier();               // chs has landed for everyone; everyone has finished reading slot chs-1
+                issue_next();                               // refills slot (chs + DIST) % 4: DIST == 3 -> the slot read in half-step chs-1
+                const char* sX = smem + (chs % NS) * SLOT;
+                const char* sW = sX + XB;
+                f16x8 wf[4], xq[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f16x8*>(sW + (wn * 64 + i * 16 + frow) * 64 + choff);
+                auto ldx = [&](int j) -> f16x8 { return *reinterpret_cast<const f16x8*>(sX + (wm * 128 + j * 16 + frow) * 64 + choff); };
+                xq[0] = ldx(0);
+                xq[1] = ldx(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
+                    if (j + 2 < 8) xq[(j + 2) % 3] = ldx(j + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j].x + acc[i][j].w;
+    if (s == 123.456f) sink[0] = s;
+}
+
+template <int V>
+static void run(const char* name, const f16* A, const f16* W, float* sink, int M, int N, int K) {
+    const size_t lds = 131072;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kloop<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (M / BM) * (N / BN);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kloop<V>), dim3(256), dim3(512), lds, 0, A, W, sink, M, N, K, tiles);
+    hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((kloop<V>), dim3(256), dim3(512), lds, 0, A, W, sink, M, N, K, tiles);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double kt = 64.0 * (K / 64);
+    printf("%-64s %8.1f us  %6.3f us per k-tile  %6.0f TFLOP/s\n", name, best * 1e3, best * 1e3 / kt, 256.0 * kt * 2.0 * 256 * 256 * 64 / (best * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+    const int K = argc > 1 ? atoi(argv[1]) : 512;
+    const int N = argc > 2 ? atoi(argv[2]) : 1536;
+    const int M = argc > 3 ? atoi(argv[3]) : 100864 / 256 * 256;
+    std::vector<f16> hA((size_t)M * K), hW((size_t)N * K);
+    unsigned x = 12345;
+    for (auto& v : hA) { x = x * 1664525u + 1013904223u; v = (f16)(((x >> 9) & 0xffff) / 65536.0f - 0.5f); }
+    for (auto& v : hW) { x = x * 1664525u + 1013904223u; v = (f16)(((x >> 9) & 0xffff) / 65536.0f - 0.5f); }
+    f16 *A, *W; float* sink;
+    hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&sink, 4);
+    hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    printf("K = %d, N = %d, M = %d (random operands), 256 workgroups x 64 tiles, no epilogue\n", K, N, M);
+    run<0>("V0 2 stages, barrier per k-tile, DMA burst behind the barrier", A, W, sink, M, N, K);
+    run<1>("V1 2 stages, barrier per k-tile, DMA spread over the MFMA groups", A, W, sink, M, N, K);
+    run<2>("V2 ring of 4 half-stages, 2 half-steps in flight", A, W, sink, M, N, K);
+    run<3>("V3 ring of 4 half-stages, 3 half-steps in flight", A, W, sink, M, N, K);
+    run<5>("V5 = V0 + fragment pipeline carried across the two k-steps", A, W, sink, M, N, K);
+    run<0>("V0 again", A, W, sink, M, N, K);
+    return 0;
+}
