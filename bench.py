@@ -59,7 +59,7 @@ def load_traffic():
     """Per-launch HBM traffic of the dominant kernel from the committed counter passes (profiles/r2_pmc_summary.json,
     written by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
     command).  None when the summary is absent."""
-    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json"):          # the newest committed counter passes
+    for name in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json"):          # the newest committed counter passes
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             break
@@ -70,6 +70,21 @@ def load_traffic():
     if not k:
         return None, f"conv1_direct_kernel missing from profiles/{name}"
     return k["hbm_bytes_per_launch"], f"profiles/{name}: " + k.get("note", "")
+
+
+def load_sq_counters():
+    """SQ / GRBM counters of the dominant kernel from the committed passes (profiles/r4_sq_summary.json, written by tools/sq_summary.py
+    from `rocprofv3 --pmc` runs of this command: tools/profile_sq.sh): MFMA-pipe busy fraction of the kernel's cycles, the clock
+    GRBM_GUI_ACTIVE implies for the dispatch, LDS bank-conflict share.  None when no summary is committed."""
+    for name in ("r4_sq_summary.json", "r4a_sq_summary.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            k = json.load(open(p)).get("conv1_direct_kernel")
+            if k:
+                return {"mfma_busy": k.get("mfma_busy_frac"), "clock_ghz_under_pmc": k.get("clock_ghz_under_pmc"),
+                        "lds_conflict_frac": k.get("lds_conflict_frac"), "lds_active_frac_of_kernel": k.get("lds_active_frac_of_kernel"),
+                        "source": f"profiles/{name} (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, one 32-clip launch under rocprofv3 --pmc)"}
+    return None
 
 
 def cpu_baseline(clips_u8, n_windows=96):
@@ -550,6 +565,7 @@ def main():
                          "algorithmic_bytes_per_launch": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch,
                          "hbm_frac_of_peak": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch / c1_avg_s / 1e9 / HBM_PEAK_GBS if c1_avg_s > 0 else None,
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n / nprof,
+                         "counters": load_sq_counters(),
                          "executed_tile_fraction": exec_frac,
                          "timing_note": "the kernel timed ALONE: these steps run on one stream (dual_stream=0, one launch = all clips); in the timed "
                                         "loop the batch runs as two parts on two streams and its two conv1 launches share the CUs with the other part's kernels",

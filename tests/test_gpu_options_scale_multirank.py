@@ -1,8 +1,8 @@
-"""GPU parity tests added in round 2 (run with -m gpu): the kernel paths and switches the first round's tests did not
-reach -- long sequences (VALU attention, T in (160,500], text L > 32), every engine option, the W2_ALL precision mode,
+"""Engine options, long sequences, scale and multi-rank (run with -m gpu): the kernel paths and switches the golden / end-to-end
+file does not reach -- long sequences (VALU attention, T in (160,500], text L > 32), every engine option, the W2_ALL precision mode,
 bias-correction calibrated on mismatched data, a non-degenerate ASD fixture from the reference's own evaluate_asd,
 the lifted spotting limits, >= 8 clips of configs 2 and 3 against the oracle, two engines in one process, and the
-2-rank sharded retrieval on the GPU.  Everything goes through the C ABI; tolerance as in test_gpu_parity.py."""
+2-rank sharded retrieval on the GPU.  Everything goes through the C ABI; tolerance as in test_gpu_golden_endtoend.py."""
 import os
 import socket
 import subprocess

@@ -1,5 +1,7 @@
-"""GPU parity tests added in round 3 (run with -m gpu): the bf16 reported mode next to the fp16 modes, the padded query rows of
-ragged JEGAL batches per precision mode, the masked upload's unpack kernel.  Everything goes through the C ABI."""
+"""Precision modes and the upload kernels (run with -m gpu): the bf16 reported mode next to the fp16 modes, the padded query rows of
+ragged JEGAL batches per precision mode, the masked upload's unpack kernel (incl. bad metadata), the source-resolution upload
+(jg_mask_resize_packed + GestureStreamer(source_hw=...)), conv1 launches with fewer strips than CUs, GEMM tile choice.
+Everything goes through the C ABI."""
 import numpy as np
 import pytest
 import torch

@@ -1,12 +1,12 @@
 #!/bin/bash
 # All rocprofv3 evidence of a round in one go (run on the GPU box through gpurun; outputs under gpurun_out/prof_<tag>/):
-#   tools/profile_round.sh r3
+#   tools/profile_round.sh r4      (tools/profile_sq.sh <tag> adds the SQ / GRBM counter passes)
 # 1. kernel trace + stats of the default bench command (two lanes) and of the one-stream mode,
 # 2. two counter passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) of one one-stream step,
 # 3. kernel trace + stats of the config-3 (B = 64 vta) measurement and of the XLM-R front end,
 # then tools/pmc_summary.py condenses 1 and 2 into profiles/<tag>_kernel_summary.csv / <tag>_pmc_summary.json.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
