@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void kloop(const f16* __restrict__ A, const f1
                 }
             }
         }
-    } else if constexpr (V == 0 || V == 1) {
+    } else if constexpr (V == 0 || V == 1 || V == 6 || V == 7) {
         constexpr int XB = BM * 128, STAGE = XB + BN * 128;
         const int lrow = lane >> 3, pc = lane & 7;
         const int fsw = (frow >> 1) & 7;
@@ -164,6 +164,14 @@ __global__ __launch_bounds__(512) void kloop(const f16* __restrict__ A, const f1
                         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
                         if (j + 2 < 8) xq[(j + 2) % 3] = ldx(j + 2);
                         if (V == 1 && (kk * 8 + j) < 8) piece(kk * 8 + j, nkt, (gk + 1) & 1);
+                        if (V == 6) {          // the two waves of a SIMD (w, w + 4) issue in DIFFERENT halves of the k-tile
+                            const int slot = kk * 8 + j - (wave >= 4 ? 8 : 0);
+                            if (slot >= 0 && slot < 8) piece(slot, nkt, (gk + 1) & 1);
+                        }
+                        if (V == 7 && j == 0 && (kk == 0) == (wave < 4)) {      // bursts, de-phased between the two waves of a SIMD
+#pragma unroll
+                            for (int p = 0; p < 8; ++p) piece(p, nkt, (gk + 1) & 1);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -285,6 +293,10 @@ int main(int argc, char** argv) {
     run<2>("V2 ring of 4 half-stages, 2 half-steps in flight", A, W, sink, M, N, K);
     run<3>("V3 ring of 4 half-stages, 3 half-steps in flight", A, W, sink, M, N, K);
     run<5>("V5 = V0 + fragment pipeline carried across the two k-steps", A, W, sink, M, N, K);
+    run<0>("V0 again", A, W, sink, M, N, K);
+    run<6>("V6 spread, the two waves of a SIMD issue in different halves", A, W, sink, M, N, K);
+    run<7>("V7 bursts, waves 0-3 at the start / waves 4-7 at mid k-tile", A, W, sink, M, N, K);
+    run<1>("V1 again", A, W, sink, M, N, K);
     run<0>("V0 again", A, W, sink, M, N, K);
     return 0;
 }
