@@ -33,14 +33,14 @@ def text_word_segments(input_ids, offset_mapping, text_batch, lengths=None):
         Lb = L if lengths is None else int(lengths[b])
         if not 0 < Lb <= L:
             raise ValueError(f"text length {Lb} of sample {b} outside 1..{L}")
-        starts = [i for i in range(Lb) if offs[b, i, 0] == 0 and int(ids[b, i]) not in SPECIAL_IDS]
-        cur, ok = [], True
-        for idx, _word in enumerate(text_batch[b]):
-            if idx >= len(starts):
-                ok = False
-                break
-            end = starts[idx + 1] if idx < len(starts) - 1 else Lb
-            cur.append((starts[idx], end))
+        # word starts: offset[0] == 0 and not <s> / </s> / <pad> (jegal.py:148-150); vectorised per sample
+        starts = np.flatnonzero((offs[b, :Lb, 0] == 0) & ~np.isin(ids[b, :Lb], SPECIAL_IDS))
+        nw = len(text_batch[b])
+        ok = nw <= len(starts)
+        cur = []
+        if ok and nw:
+            ends = np.append(starts[1:], Lb)                       # the LAST detected start runs to the end (jegal.py:168-171)
+            cur = list(zip(starts[:nw].tolist(), ends[:nw].tolist()))
         if not ok or len(cur) == 0:
             invalid.append(b)
             segs.append(None)
