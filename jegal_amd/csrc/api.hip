@@ -181,6 +181,12 @@ struct DeviceGuard {
 };
 #define ENTER(h) if (!(h)) return JG_ERR_ARG; DeviceGuard _dg((h)->device); if (!_dg.ok) JG_FAIL(h, JG_ERR_HIP, "hipSetDevice(%d) failed", (h)->device)
 
+// env JG_DEBUG_SYNC, read once per process: synchronise (and report) after every launch
+inline bool debug_sync() {
+    static const bool on = getenv("JG_DEBUG_SYNC") != nullptr;
+    return on;
+}
+
 // run a launcher under optional event timing
 template <class F>
 int timed(jg_handle* h, int stage, F&& f) {
@@ -193,12 +199,12 @@ int timed(jg_handle* h, int stage, F&& f) {
     }
     hipError_t e = f();
     if (e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "kernel launch failed (stage %s): %s", jg_stage_name(stage), hipGetErrorString(e));
-    static const bool dbg_sync = getenv("JG_DEBUG_SYNC") != nullptr;      // fault hunting: name the launch a memory fault belongs to
-    if (dbg_sync) {
+    if (debug_sync()) {                          // fault hunting (env JG_DEBUG_SYNC): name the launch a memory fault belongs to
         static long n = 0;
         std::fprintf(stderr, "[jg] launch %ld (stage %s) ...", ++n, jg_stage_name(stage));
         e = hipStreamSynchronize(h->stream);
         std::fprintf(stderr, " %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+        if (e != hipSuccess) JG_FAIL(h, JG_ERR_HIP, "launch %ld (stage %s) failed at its synchronisation: %s", n, jg_stage_name(stage), hipGetErrorString(e));
     }
     if (prof) {
         HIPCHK(h, hipEventRecord(r.e1, h->stream));
@@ -555,7 +561,7 @@ constexpr int FH = 270, FW = 480;
 // fill_all = false: the caller's conv2 honours the row skip the scan leaves in zscr, so the pooled rows it never reads stay unwritten
 int conv1_from_frames(jg_handle* h, const uint8_t* src, int nclip, int T, int pad, f16* pooled, f16* edge, unsigned* zscr, bool fill_all) {
     const bool scan = h->opts.conv1_zero_skip;
-    if (getenv("JG_DEBUG_SYNC")) {
+    if (debug_sync()) {
         const long NFd = (long)nclip * (T + 2 * pad - 4);
         std::fprintf(stderr, "[jg] conv1: src %p..%p pooled %p..%p edge %p..%p zscr %p..%p fill_all %d\n", (const void*)src,
                      (const void*)(src + (size_t)nclip * T * FH * FW * 3), (void*)pooled, (void*)(pooled + (size_t)NFd * 43 * 78 * 64), (void*)edge,

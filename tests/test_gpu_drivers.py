@@ -227,7 +227,7 @@ def _oracle_alone(jsd, c, mod):
     return (None if g is None else O.l2_normalize(g[0]).numpy(), None if cemb is None else O.l2_normalize(cemb[0]).numpy())
 
 
-@pytest.mark.parametrize("mod", ["vta", "ta", "a", "t"])
+@pytest.mark.parametrize("mod", ["vta", "ta", "a", "t", "vt", "va", "v"])
 def test_extract_jegal_embs_is_batch_invariant_on_ragged_clips(tmp_path, mod):
     """the reference's dataset driver runs ONE clip per step (evaluation/extract_jegal_embs.py:141); this
     driver batches 16.  Sixteen ragged clips (T 25..220, W 3..12, every last word multi-sub-word and ending on the clip's last
@@ -258,6 +258,9 @@ def test_extract_jegal_embs_is_batch_invariant_on_ragged_clips(tmp_path, mod):
             worst_g = max(worst_g, rel(f["gesture_emb"], g))
         else:
             assert f["gesture_emb"] is None
+        if ce is None:                                   # --modalities v: gesture only
+            assert f["content_emb"] is None
+            continue
         assert f["content_emb"].shape == (W, 512)
         worst_c = max(worst_c, rel(f["content_emb"], ce))
         worst_last = max(worst_last, float(np.abs(f["content_emb"][-1] - ce[-1]).max()))
