@@ -151,7 +151,8 @@ struct jg_handle {
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
     size_t feats_cap = 0;
-    std::vector<int32_t> audio_valid;   // host copy of the last jg_jegal_audio_ragged call's valid lengths (source of a stream-ordered upload)
+    std::vector<int32_t> audio_valid[4];   // host copies of the last four jg_jegal_audio_ragged calls' valid lengths (sources of stream-ordered uploads)
+    unsigned audio_valid_next = 0;
     // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
@@ -1049,9 +1050,10 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, const int32_
             ragged |= valid_host[b] != Tm;
         }
         if (ragged) {
-            h->audio_valid.assign(valid_host, valid_host + B);          // stays alive until the next call: the copy below is stream-ordered
+            std::vector<int32_t>& hv = h->audio_valid[h->audio_valid_next++ & 3];      // stays alive for three more calls: the copy is stream-ordered
+            hv.assign(valid_host, valid_host + B);
             RET(wsalloc(h, (size_t)B, &valid));
-            HIPCHK(h, hipMemcpyAsync(valid, h->audio_valid.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(valid, hv.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
         }
     }
     f16 *c0, *c3, *c6, *c9, *c12, *c15;
