@@ -8,9 +8,9 @@
 
 Same flags, file naming and on-disk formats as the reference.  What is upstream of the hot path is
 NOT rebuilt: video decoding / mediapipe masking (the drivers read already masked 270x480 crops as
-``<frames_dir>/<vid>/<track>.npy`` uint8 (T,270,480,3)), wav -> log-mel (``<video_dir>/<file>.mel.npy``
-(4T,80) fp32, librosa is third-party) and XLM-RoBERTa (``--text_states_dir`` with
-``<vid>__<track>.npz`` holding states/mask/ids/offsets, or a ``text_encoder`` passed from Python).
+``<frames_dir>/<vid>/<track>.npy`` uint8 (T,270,480,3)) and XLM-RoBERTa's tokenizer; audio is read as the reference reads it
+(``<video_dir>/<file>.wav`` -> log-mel on the GPU, or a precomputed ``<file>.mel.npy`` (4T,80) fp32); XLM-RoBERTa states come from
+``--text_states_dir`` (``<vid>__<track>.npz`` holding states/mask/ids/offsets) or a ``text_encoder`` passed from Python.
 Run under ``torchrun`` to shard over GPUs (contiguous blocks, extract_gestsync_feats.py:366-370).
 """
 import argparse
@@ -225,11 +225,23 @@ def cmd_extract_jegal_embs(argv):
                 if item["feats"].ndim != 2 or item["feats"].shape[1] != 1024:
                     continue
             if "a" in mod:
+                # the reference's dataset reads <video_dir>/<file>.wav and computes the log-mel itself (dataset.py:229-235,279-298);
+                # a precomputed <file>.mel.npy (4T,80) takes precedence, else the .wav goes through the GPU front end (jg_logmel)
                 fn = os.path.join(args.video_dir, row.filename + ".mel.npy")
-                if not os.path.exists(fn):
-                    print("Audio file does not exist: ", fn)
+                wav_fn = os.path.join(args.video_dir, row.filename + ".wav")
+                if os.path.exists(fn):
+                    item["mel"] = np.load(fn).astype(np.float32)
+                elif os.path.exists(wav_fn):
+                    try:
+                        from . import audio as jaudio
+                        wav = torch.from_numpy(np.asarray(jaudio.load_wav(wav_fn)).astype(np.float32))
+                        item["mel"] = jaudio.wav2filterbanks(wav[None].to(eng.device), engine=eng)[0][0].cpu().numpy()
+                    except Exception:                      # dataset.py:296-298: a wav that cannot be read drops the sample
+                        print("Error loading audio, check the file: ", wav_fn)
+                        continue
+                else:
+                    print("Audio file does not exist: ", wav_fn)
                     continue
-                item["mel"] = np.load(fn).astype(np.float32)
             if "t" in mod:
                 fn = os.path.join(args.text_states_dir or args.video_dir, row.filename.replace("/", "__") + ".npz")
                 if not os.path.exists(fn):

@@ -327,3 +327,40 @@ def test_forward_inference_default_keeps_the_reference_semantics_at_b_gt_1():
     assert float((ref_batch[0, 2] - alone_raw[2]).abs().max()) > 1e-2
     with pytest.raises(ValueError):
         jg.forward_inference(text=pack, audio=torch.from_numpy(mel), word_boundaries=wbs, per_clip=True)       # audio_lens missing
+
+
+def test_extract_jegal_embs_reads_wav_like_the_reference(tmp_path):
+    """The reference's dataset reads <video_dir>/<file>.wav and computes the log-mel itself (dataset.py:229-235,279-298).  The driver
+    does the same through the GPU front end (jg_logmel) when no precomputed .mel.npy exists: the reference's own samples/sample1.wav
+    (data fixture, 34691 samples -> 216 mel frames -> 54 audio steps) in an `a`-only run equals the oracle chain wav -> mel (torch.stft)
+    -> forward_audio -> word pooling -> fusion; an unreadable wav drops the sample as the reference does."""
+    import shutil
+    import pandas as pd
+    from jegal_amd import audio
+    video_dir, res_dir = str(tmp_path / "videos"), str(tmp_path / "res")
+    os.makedirs(os.path.join(video_dir, "vidA_0-2"))
+    os.makedirs(os.path.join(video_dir, "vidB_0-2"))
+    wav_src = os.path.join(os.path.dirname(__file__), "golden", "sample1.wav")
+    shutil.copy(wav_src, os.path.join(video_dir, "vidA_0-2", "00000.wav"))
+    with open(os.path.join(video_dir, "vidB_0-2", "00000.wav"), "wb") as f:
+        f.write(b"not a wav file")
+    wb = [["amount", 1, 6], ["of", 7, 9], ["water", 10, 20], ["in", 21, 23], ["the", 40, 53]]
+    rows = [{"video_id": v, "filename": f"{v}/00000", "phrase": " ".join(w[0] for w in wb), "word_boundaries": str(wb), "target_word_boundary": str(wb[0])}
+            for v in ("vidA_0-2", "vidB_0-2")]
+    csv = str(tmp_path / "avs.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    assert drivers.main(["extract_jegal_embs", "--file_path", csv, "--checkpoint_path", "synthetic", "--res_dir", res_dir, "--video_dir", video_dir,
+                         "--feature_dir", video_dir, "--modalities", "a"]) == 0
+    files = sorted(os.listdir(os.path.join(res_dir, "a")))
+    assert files == ["vidA_0-2__00000.pkl"]                              # the broken wav was dropped
+    got = pickle.load(open(os.path.join(res_dir, "a", files[0]), "rb"))
+    assert got["gesture_emb"] is None and got["content_emb"].shape == (5, 512)
+    wav = audio.load_wav(wav_src).astype(np.float32)
+    mel = O.wav2filterbanks(wav[None], torch.from_numpy(audio.mel_filterbank()))
+    assert mel.shape == (1, 216, 80)
+    jsd = O.tensors(synth.jegal_state_dict())
+    with torch.no_grad():
+        ref = O.l2_normalize(O.jegal_forward_inference(jsd, audio=mel, word_boundaries=[wb])[0]).numpy()
+    r = float(np.linalg.norm(got["content_emb"] - ref) / np.linalg.norm(ref))
+    print(f"\nwav -> content embedding through the driver vs the oracle chain: rel-L2 {r:.2e}")
+    assert r < 1e-3
