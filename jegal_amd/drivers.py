@@ -185,6 +185,23 @@ def cmd_extract_gestsync_feats(argv):
 
 
 # --------------------------------------------------------------------------- extract_jegal_embs
+def _load_tokenizer(name):
+    """The reference's module global `tokenizer = AutoTokenizer.from_pretrained("xlm-roberta-base")` (models/jegal.py:13): third-party,
+    host side.  `name` is a HuggingFace name or a local directory (no network on the GPU boxes: pass a directory)."""
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(name)
+
+
+def _load_xlmr(eng, path):
+    """`mroberta = XLMRobertaModel.from_pretrained("xlm-roberta-base")` (models/jegal.py:14) on the engine: `path` = a state_dict of
+    transformers.XLMRobertaModel (torch.save) or 'synthetic' (seeded test weights, reduced vocabulary)."""
+    from .xlmr import XLMRoberta
+    sd = synth.xlmr_state_dict() if path == "synthetic" else torch.load(path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return XLMRoberta(engine=eng).load_state_dict({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in sd.items()})
+
+
 def _load_text_pack(path):
     z = np.load(path, allow_pickle=True)
     return z["states"], z["mask"], z["ids"], z["offsets"]
@@ -198,12 +215,20 @@ def cmd_extract_jegal_embs(argv):
     p.add_argument("--res_dir", required=True)
     p.add_argument("--video_dir", required=True)
     p.add_argument("--feature_dir", required=True)
-    p.add_argument("--text_states_dir", default=None)
+    p.add_argument("--text_states_dir", default=None, help="precomputed XLM-RoBERTa states <vid>__<track>.npz (states, mask, ids, offsets)")
+    p.add_argument("--xlmr_checkpoint", default=None, help="state_dict of transformers.XLMRobertaModel (or 'synthetic'): run XLM-RoBERTa on the engine "
+                                                           "from the csv's phrases, as models/jegal.py:116-129 does on the CPU; needs --tokenizer")
+    p.add_argument("--tokenizer", default=None, help="HuggingFace tokenizer name or local directory (models/jegal.py:13: xlm-roberta-base)")
     p.add_argument("--modalities", default="vta", choices=["vta", "vt", "va", "ta", "v", "t", "a"])
     p.add_argument("--batch_size", type=int, default=16, help="clips per engine call (the reference: 1; results are those of batch size 1 whatever this is)")
     _add_precision_args(p)
     args = p.parse_args(argv)
     eng, _, jg = _models(args, need_jegal=True)
+    xlmr = tok = None
+    if "t" in args.modalities and args.xlmr_checkpoint:
+        if not args.tokenizer:
+            raise SystemExit("--xlmr_checkpoint needs --tokenizer (a HuggingFace name or a local tokenizer directory)")
+        xlmr, tok = _load_xlmr(eng, args.xlmr_checkpoint), _load_tokenizer(args.tokenizer)
     df = pd.read_csv(args.file_path)
     print("Total files: {}".format(len(df)))
     res_dir = os.path.join(args.res_dir, args.modalities)
@@ -242,7 +267,7 @@ def cmd_extract_jegal_embs(argv):
                 else:
                     print("Audio file does not exist: ", wav_fn)
                     continue
-            if "t" in mod:
+            if "t" in mod and xlmr is None:
                 fn = os.path.join(args.text_states_dir or args.video_dir, row.filename.replace("/", "__") + ".npz")
                 if not os.path.exists(fn):
                     print("Text states file does not exist: ", fn)
@@ -267,7 +292,12 @@ def cmd_extract_jegal_embs(argv):
             audio = torch.zeros((n, Tm, 80))
             for i, it in enumerate(batch):
                 audio[i, :it["mel"].shape[0]] = torch.from_numpy(it["mel"])
-        if "t" in mod:
+        if "t" in mod and xlmr is not None:
+            # phrases -> tokenizer (host) -> XLM-RoBERTa on the engine: get_roberta_embeddings (models/jegal.py:116-129) for the whole
+            # batch; the key padding mask and the position ids from the non-pad tokens keep every clip's rows independent of the padding
+            from .xlmr import roberta_embeddings
+            text = roberta_embeddings(xlmr, tok, [str(it["row"].phrase) for it in batch])
+        elif "t" in mod:
             L = max(it["text"][0].shape[0] for it in batch)
             st = np.zeros((n, L, 768), np.float32)
             tm = np.zeros((n, L), np.int64)

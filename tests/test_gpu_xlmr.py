@@ -192,3 +192,40 @@ def test_xlmr_calibration_is_explicit_and_holds_on_other_token_distributions():
     with pytest.raises(JegalError):
         m2.calibrate()
     e2.close()
+
+
+def test_dataset_driver_runs_xlmr_on_the_engine_batch_invariant(tmp_path, monkeypatch):
+    """`extract_jegal_embs --modalities t --xlmr_checkpoint ... --tokenizer ...`: phrases from the csv -> tokenizer (host; a stub with
+    the HuggingFace calling convention, the sentencepiece model is not available offline) -> XLM-RoBERTa on the engine -> JEGAL
+    text encoder -> word pooling -> fusion, eight sentences of 1..9 words in ONE padded batch.  Every .pkl must be what the oracle
+    chain (fp32 XLM-R restatement + fp32 JEGAL restatement) gives for that sentence ALONE (models/jegal.py:116-129,168-171;
+    evaluation/extract_jegal_embs.py:141 runs batch_size=1)."""
+    import pickle
+    import pandas as pd
+    from jegal_amd import drivers
+    monkeypatch.setattr(drivers, "_load_tokenizer", lambda name: StubTokenizer())
+    phrases = ["hello", "so we went over there yesterday", "and then it suddenly stopped working", "two words", "a b c d e f g h i",
+               "extraordinarily long wordforms everywhere", "yes", "the quick brown fox jumps"]
+    rows = []
+    for i, ph in enumerate(phrases):
+        wb = [[w, 5 * j, 5 * j + 4] for j, w in enumerate(ph.split(" "))]
+        rows.append({"video_id": f"vid{i}", "filename": f"vid{i}/00000", "phrase": ph, "word_boundaries": str(wb), "target_word_boundary": str(wb[0])})
+    csv = str(tmp_path / "avs.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    res_dir = str(tmp_path / "res")
+    assert drivers.main(["extract_jegal_embs", "--file_path", csv, "--checkpoint_path", "synthetic", "--res_dir", res_dir, "--video_dir", str(tmp_path),
+                         "--feature_dir", str(tmp_path), "--modalities", "t", "--xlmr_checkpoint", "synthetic", "--tokenizer", "stub", "--batch_size", "8"]) == 0
+    jsd = O.tensors(synth.jegal_state_dict())
+    xsd = synth.xlmr_state_dict()
+    tok = StubTokenizer()
+    worst = 0.0
+    for i, ph in enumerate(phrases):
+        got = pickle.load(open(os.path.join(res_dir, "t", f"vid{i}__00000.pkl"), "rb"))["content_emb"]
+        enc = tok([ph.split(" ")])
+        with torch.no_grad():
+            states = O.xlmr_forward(xsd, enc["input_ids"].numpy(), enc["attention_mask"].numpy())
+            ref = O.l2_normalize(O.jegal_forward_inference(jsd, text=(states, enc["attention_mask"], [ph.split(" ")], enc["input_ids"], enc["offset_mapping"]))[0]).numpy()
+        assert got.shape == ref.shape == (len(ph.split(" ")), 512)
+        worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+    print(f"\nphrases -> XLM-R on the engine -> content embeddings, 8 ragged sentences in one batch vs the oracle on each alone: rel-L2 {worst:.2e}")
+    assert worst < TOL
