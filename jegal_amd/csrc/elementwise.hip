@@ -824,7 +824,9 @@ hipError_t launch_mask_resize(const uint8_t* src, int T, int H, int W, const int
     // source rows a band of MR_RB output rows can touch: (MR_RB - 1) * H / 270 + 3
     const long span_rows = (long)(MR_RB - 1) * H / 270 + 3;
     static const bool generic = getenv("JG_MASK_RESIZE_GENERIC") != nullptr;       // A/B and test switch
-    if (span_rows * W * 3 + 4 <= MR_SPAN_MAX && W <= 32767 && !generic) {
+    // (the banded kernel stages dword-aligned spans: it may read up to 3 bytes in front of a row that does not start on a dword, which
+    // is inside the buffer as long as the buffer itself starts on one)
+    if (span_rows * W * 3 + 4 <= MR_SPAN_MAX && W <= 32767 && !generic && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
         const size_t lds = (size_t)MR_RB * 480 * 3 + (((size_t)span_rows * W * 3 + 4 + 15) & ~(size_t)15);
         hipLaunchKernelGGL(mask_resize_band_kernel, dim3((unsigned)(T * (270 / MR_RB))), dim3(256), lds, s, src, T, H, W, mask_y_dev, dst, offs, src_bytes);
         return hipGetLastError();
