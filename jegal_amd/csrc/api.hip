@@ -59,6 +59,11 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     long mu_rows = 0;
     int model = 0;              // 1 GestSync, 2 JEGAL (which finalize owns this layer)
     std::vector<float> w32, b32;
+    // Linear behind an IMPLICIT LayerNorm (GemmArgs::ln_mode 1): w32 / wh / wl hold W . diag(gamma), b32 / bias hold b + W beta, and
+    // c1h / c1f [N] the column sums of the packed weights -- of `wh` alone (single-fp16 runs: the GEMM then is exactly
+    // sum_k wh[n][k] (x[k] - mean) rstd, and the bias correction covers the lo part) and of wh + lo (hi+lo runs)
+    float* c1h = nullptr;
+    float* c1f = nullptr;
 };
 struct LNp { float* w = nullptr; float* b = nullptr; };
 
@@ -147,6 +152,9 @@ struct jg_handle {
     float *xl_word = nullptr, *xl_pos = nullptr, *xl_type = nullptr;
     LNp xl_emb_ln;
     std::vector<EncLayer> xl_layers;
+    // implicit LayerNorm (option "xlmr_fold", read when the XLM-R weights are finalized): the 25 LayerNorms of a pass are never
+    // materialised -- see xlmr_encode_folded
+    bool xl_fold_opt = true, xl_folded = false;
     std::vector<void*> wallocs_xl;
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
@@ -258,7 +266,7 @@ int need(jg_handle* h, const std::string& name, int64_t numel, const HostTensor*
 // layer kinds: which precision treatment a matrix gets under the handle's mode
 enum { LK_CONV = 0, LK_GESTURE = 1, LK_CONTENT = 2, LK_XLMR = 3 };      // LK_XLMR: bias-corrected like the gesture path (calibrated on token ids)
 
-int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L) {
+int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L, bool ln_consumer = false) {
     const int mode = h->precision;
     const bool bc = mode == JG_PREC_FP16_BC && (kind == LK_GESTURE || kind == LK_XLMR);
     const bool split = kind == LK_CONV ? mode == JG_PREC_FP16_W2_ALL
@@ -279,6 +287,31 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     }
     L->N = N; L->K = K;
     L->model = h->cur_model;
+    L->c1h = L->c1f = nullptr;
+    if (ln_consumer) {            // column sums of the weights AS PACKED (Lin::c1h / c1f)
+        std::vector<float> c1h(N), c1f(N);
+        for (int n = 0; n < N; ++n) {
+            double sh = 0.0, sl = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const size_t i = (size_t)n * K + k;
+                if (h->bf16) {
+                    uint16_t b;
+                    std::memcpy(&b, &hi[i], 2);
+                    const uint32_t u = (uint32_t)b << 16;
+                    float f;
+                    std::memcpy(&f, &u, 4);
+                    sh += (double)f;
+                } else {
+                    sh += (double)(float)hi[i];
+                    if (!lo.empty()) sl += (double)(float)lo[i];
+                }
+            }
+            c1h[n] = (float)sh;
+            c1f[n] = (float)(sh + sl);
+        }
+        RET(upload(h, c1h, &L->c1h));
+        RET(upload(h, c1f, &L->c1f));
+    }
     RET(upload(h, hi, &L->wh));
     L->wl = nullptr;
     if (split) RET(upload(h, lo, &L->wl));
@@ -505,6 +538,15 @@ struct Epi {
     signed char* out8 = nullptr;
     int a_tiled = 0;
     int no_bias = 0;              // the layer's bias is applied elsewhere (layer-0 qkv by linearity: it rides in the projected PE rows)
+    // implicit LayerNorm (GemmArgs::ln_mode): ln_stats = (mean, rstd) of the LayerNorm's input rows.  Mode 1: the layer is a folded
+    // consumer (Lin::c1h / c1f).  Mode 2: x_hi / x_lo = the token stream's planes (residual in, new rows out, in place),
+    // ln_gamma = that LayerNorm's weight (its bias is already part of the layer's packed bias), stat_out = the new rows' partial sums.
+    int ln_mode = 0;
+    const float* ln_stats = nullptr;
+    f16* x_hi = nullptr;
+    f16* x_lo = nullptr;
+    const float* ln_gamma = nullptr;
+    float* stat_out = nullptr;
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -520,6 +562,13 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     a.relu = e.relu;
     if (e.ln) { a.ln_w = e.ln->w; a.ln_b = e.ln->b; a.ln_flavour = e.ln_flavour; }
     a.res16 = e.res16; a.res8 = e.res8; a.out8 = e.out8; a.a_tiled = e.a_tiled;
+    if (e.ln_mode == 1) {
+        if (!L.c1h || !L.c1f) JG_FAIL(h, JG_ERR_STATE, "implicit LayerNorm on a layer that was not packed for it");
+        a.ln_mode = 1; a.ln_stats = e.ln_stats; a.scale = a.Wl ? L.c1f : L.c1h;
+    } else if (e.ln_mode == 2) {
+        a.ln_mode = 2; a.ln_stats = e.ln_stats; a.scale = e.ln_gamma;
+        a.xres_hi = e.x_hi; a.xres_lo = e.x_lo; a.out16 = e.x_hi; a.out_lo = e.x_lo; a.stat_out = e.stat_out;
+    }
     const bool conv = g != nullptr;
     if (h->calib && L.bc && !conv) {
         // column sums ACCUMULATE over every call of a calibration pass (chunks of a large calibration batch, the six
@@ -527,7 +576,8 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
         Lin& Lm = const_cast<Lin&>(L);
         float* part;
         RET(wsalloc(h, col_sum_scratch_elems(L.K), &part));
-        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, part, Lm.mu, h->stream); }));
+        // (a folded consumer's effective input is the NORMALISED row: the correction term is (w' - fp16(w')) . E[(x - mean) rstd])
+        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, part, Lm.mu, h->stream, e.ln_mode == 1 ? e.ln_stats : nullptr); }));
         Lm.mu_rows += M;
     }
     return timed(h, stage, [&] { return LAUNCH(h, launch_gemm, a, conv, h->opts, h->stream); });
@@ -1120,6 +1170,32 @@ int finalize_xlmr(jg_handle* h) {
     RET(need(h, "xlmr.embeddings.token_type_embeddings.weight", D, &t));
     RET(upload(h, t->v, &h->xl_type));
     RET(make_ln(h, "xlmr.embeddings.LayerNorm.weight", "xlmr.embeddings.LayerNorm.bias", D, &h->xl_emb_ln));
+    // Implicit LayerNorm (xlmr_encode_folded): the Linear BEHIND a LayerNorm(gamma, beta) is packed as W diag(gamma) with bias
+    // b + W beta (fold_consumer), the Linear whose output is ADDED to that LayerNorm's output takes beta into its bias (the
+    // gamma (x - mean) rstd part is recomputed from the un-normalised stream in its epilogue).
+    const bool fold = h->xl_fold_opt;
+    const HostTensor *pg, *pb;          // the LayerNorm in front of the current sub-layer
+    RET(need(h, "xlmr.embeddings.LayerNorm.weight", D, &pg));
+    RET(need(h, "xlmr.embeddings.LayerNorm.bias", D, &pb));
+    auto fold_consumer = [](std::vector<float>& w, std::vector<float>& b, int N, int K, const std::vector<float>& g, const std::vector<float>& be) {
+        for (int n = 0; n < N; ++n) {
+            double acc = 0.0;
+            float* wr = &w[(size_t)n * K];
+            for (int k = 0; k < K; ++k) {
+                acc += (double)wr[k] * (double)be[k];
+                wr[k] *= g[k];
+            }
+            b[n] = (float)((double)b[n] + acc);
+        }
+    };
+    auto make_producer = [&](const std::string& wname, const std::string& bname, int N, int K, const std::vector<float>& be, Lin* Lo) -> int {
+        const HostTensor *w, *b;
+        RET(need(h, wname, (int64_t)N * K, &w));
+        RET(need(h, bname, N, &b));
+        std::vector<float> bb = b->v;
+        for (int n = 0; n < N; ++n) bb[n] += be[n];
+        return pack_matrix(h, w->v, bb, N, K, LK_XLMR, Lo);
+    };
     int nl = 0;
     while (find(h, "xlmr.encoder.layer." + std::to_string(nl) + ".attention.self.query.weight")) ++nl;
     if (nl == 0) JG_FAIL(h, JG_ERR_WEIGHT, "no 'xlmr.encoder.layer.*' weights");
@@ -1136,23 +1212,97 @@ int finalize_xlmr(jg_handle* h) {
             std::memcpy(&w[(size_t)i * D * D], wi->v.data(), sizeof(float) * D * D);
             std::memcpy(&b[(size_t)i * D], bi->v.data(), sizeof(float) * D);
         }
-        RET(pack_matrix(h, w, b, 3 * D, D, LK_XLMR, &L->qkv));
-        RET(make_linear(h, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, &L->out, LK_XLMR));
+        if (!fold) {
+            RET(pack_matrix(h, w, b, 3 * D, D, LK_XLMR, &L->qkv));
+            RET(make_linear(h, p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, &L->out, LK_XLMR));
+            RET(make_ln(h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", D, &L->n1));
+            RET(make_linear(h, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", DFF, D, &L->ff1, LK_XLMR));
+            RET(make_linear(h, p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, &L->ff2, LK_XLMR));
+            RET(make_ln(h, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", D, &L->n2));
+            continue;
+        }
+        fold_consumer(w, b, 3 * D, D, pg->v, pb->v);
+        RET(pack_matrix(h, w, b, 3 * D, D, LK_XLMR, &L->qkv, true));
+        RET(make_producer(p + ".attention.output.dense.weight", p + ".attention.output.dense.bias", D, D, pb->v, &L->out));
         RET(make_ln(h, p + ".attention.output.LayerNorm.weight", p + ".attention.output.LayerNorm.bias", D, &L->n1));
-        RET(make_linear(h, p + ".intermediate.dense.weight", p + ".intermediate.dense.bias", DFF, D, &L->ff1, LK_XLMR));
-        RET(make_linear(h, p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, &L->ff2, LK_XLMR));
+        RET(need(h, p + ".attention.output.LayerNorm.weight", D, &pg));
+        RET(need(h, p + ".attention.output.LayerNorm.bias", D, &pb));
+        {
+            const HostTensor *w1, *b1;
+            RET(need(h, p + ".intermediate.dense.weight", (int64_t)DFF * D, &w1));
+            RET(need(h, p + ".intermediate.dense.bias", DFF, &b1));
+            std::vector<float> wf = w1->v, bf1 = b1->v;
+            fold_consumer(wf, bf1, DFF, D, pg->v, pb->v);
+            RET(pack_matrix(h, wf, bf1, DFF, D, LK_XLMR, &L->ff1, true));
+        }
+        RET(make_producer(p + ".output.dense.weight", p + ".output.dense.bias", D, DFF, pb->v, &L->ff2));
         RET(make_ln(h, p + ".output.LayerNorm.weight", p + ".output.LayerNorm.bias", D, &L->n2));
+        RET(need(h, p + ".output.LayerNorm.weight", D, &pg));
+        RET(need(h, p + ".output.LayerNorm.bias", D, &pb));
     }
     h->xl_layers_n = nl;
+    h->xl_folded = fold;
     h->xl_ready = true;
     return JG_OK;
 }
 
 // XLMRobertaModel.forward(input_ids, attention_mask).last_hidden_state: post-norm BERT layers (LayerNorm eps 1e-5, exact GELU),
 // the key padding mask of attention_mask, position ids from the non-pad tokens (padding_idx = 1).
+// The same forward pass with IMPLICIT LayerNorms (option xlmr_fold, default): post-norm layers x' = LN(x + f(x)) are carried as the
+// UN-normalised sums x (two fp16 planes hi + lo; hi is the next GEMM's A operand) plus (mean, rstd) per row.  A Linear behind a
+// LayerNorm runs on x with W diag(gamma) and finishes rstd (acc - mean c1) + (b + W beta) in its epilogue; a Linear whose output is
+// added to LN(x) recomputes gamma (x - mean) rstd + beta from the planes there, writes the new planes in place and the per-64-column
+// (sum, sum of squares) of the new rows; launch_ln_stats (one thread per row) makes the next (mean, rstd).  Per pass: 25 LayerNorm
+// launches over fp32 rows (10 % of the time, 18 B per element and sub-layer through HBM) become 24 x 3 us and 8 B per element.
+int xlmr_encode_folded(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
+    constexpr int D = 768, DFF = 3072, H = 12, P = D / 64;
+    const int M = B * L;
+    const int Mp = M < 128 ? 128 : M;             // the LDS-DMA GEMMs want >= 128 rows: short batches carry zero rows behind the tokens
+    float *part, *stats, *mk = nullptr;
+    f16 *xh, *xl, *qkv, *att, *hid;
+    RET(wsalloc(h, (size_t)Mp * D, &xh));
+    RET(wsalloc(h, (size_t)Mp * D, &xl));
+    RET(wsalloc(h, (size_t)Mp * P * 2, &part));
+    RET(wsalloc(h, (size_t)Mp * 2, &stats));
+    RET(wsalloc(h, (size_t)Mp * 3 * D, &qkv));
+    RET(wsalloc(h, (size_t)Mp * D, &att));
+    RET(wsalloc(h, (size_t)Mp * DFF, &hid));
+    if (Mp > M) {
+        HIPCHK(h, hipMemsetAsync(xh + (size_t)M * D, 0, (size_t)(Mp - M) * D * sizeof(f16), h->stream));
+        HIPCHK(h, hipMemsetAsync(xl + (size_t)M * D, 0, (size_t)(Mp - M) * D * sizeof(f16), h->stream));
+        HIPCHK(h, hipMemsetAsync(part + (size_t)M * P * 2, 0, (size_t)(Mp - M) * P * 2 * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(att + (size_t)M * D, 0, (size_t)(Mp - M) * D * sizeof(f16), h->stream));
+    }
+    if (amask) {
+        RET(wsalloc(h, (size_t)M, &mk));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_mask_i32_f32(amask, mk, M, h->stream); }));
+    }
+    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_xlmr_embed_planes, ids, B, L, D, 1, h->xl_vocab, h->xl_maxpos, h->xl_word, h->xl_pos, h->xl_type, xh, xl, part, h->stream); }));
+    auto ln_stats = [&]() { return timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_ln_stats, part, Mp, P, stats, h->stream); }); };
+    RET(ln_stats());
+    const LNp* prev = &h->xl_emb_ln;
+    for (int l = 0; l < h->xl_layers_n; ++l) {
+        const EncLayer& Ly = h->xl_layers[l];
+        Epi q; q.out16 = qkv; q.ln_mode = 1; q.ln_stats = stats;
+        RET(gemm(h, JG_ST_GEMM, xh, D, Mp, Ly.qkv, q));
+        RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mk, B, L, H, 64, att, h->opts, h->stream); }));
+        Epi o; o.ln_mode = 2; o.ln_stats = stats; o.x_hi = xh; o.x_lo = xl; o.ln_gamma = prev->w; o.stat_out = part;
+        RET(gemm(h, JG_ST_GEMM, att, D, Mp, Ly.out, o));
+        RET(ln_stats());
+        Epi f; f.relu = 2; f.out16 = hid; f.ln_mode = 1; f.ln_stats = stats;
+        RET(gemm(h, JG_ST_GEMM, xh, D, Mp, Ly.ff1, f));
+        o.ln_gamma = Ly.n1.w;
+        RET(gemm(h, JG_ST_GEMM, hid, DFF, Mp, Ly.ff2, o));
+        if (l + 1 < h->xl_layers_n) RET(ln_stats());
+        prev = &Ly.n2;
+    }
+    return timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm_planes, xh, xl, prev->w, prev->b, M, D, out, h->stream); });
+}
+
 int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
     if (!h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "XLM-RoBERTa weights not finalized (jg_finalize_weights(h, 4))");
     if (B <= 0 || L <= 0 || L > h->xl_maxpos - 2) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < L <= %d", h->xl_maxpos - 2);
+    if (h->xl_folded) return xlmr_encode_folded(h, ids, amask, B, L, out);
     constexpr int D = 768, DFF = 3072, H = 12;
     const int M = B * L;
     float *x32, *t32, *mk = nullptr;
@@ -1207,17 +1357,18 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
 // one part on h->stream / h->ws, which are the current lane's while it is called.  Entry: both lane streams wait for the caller's
 // stream; exit: the caller's stream waits for both lanes.  Small batches run as one part on the caller's stream.
 template <class F>
-int run_in_lanes(jg_handle* h, int B, int T, F&& run_part) {
+int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int split = 0) {
+    const int sp = split ? split : h->dual_split;        // eighths of the batch on the first lane
     // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
     // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
-    if (!h->dual_stream || h->calib || B < 8 || (long)((B * h->dual_split + 4) / 8) * T < 256) return run_part(0, B);
+    if (!h->dual_stream || h->calib || B < 8 || (long)((B * sp + 4) / 8) * T < 256) return run_part(0, B);
     for (int l = 0; l < 2; ++l)
         if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
     for (int e = 0; e < 3; ++e)
         if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
     hipStream_t user = h->stream;
     HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
-    const int B0 = (B * h->dual_split + 4) / 8;
+    const int B0 = (B * sp + 4) / 8;
     int rc = JG_OK;
     for (int l = 0; l < 2 && rc == JG_OK; ++l) {
         if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
@@ -1324,6 +1475,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "xlmr_fold")) { h->xl_fold_opt = value != 0; return JG_OK; }       // takes effect at the next jg_finalize_weights(h, 4)
     if (!std::strcmp(name, "dual_split")) {
         if (value < 1 || value > 7) JG_FAIL(h, JG_ERR_ARG, "dual_split must be 1..7 (eighths of the batch on the first lane)");
         h->dual_split = value;
@@ -1584,8 +1736,15 @@ int jg_jegal_text(jg_handle* h, const float* states, const float* mask, int B, i
 int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L, float* out) {
     ENTER(h);
     if (!input_ids || !out) JG_FAIL(h, JG_ERR_ARG, "null buffer");
-    h->ws.reset();
-    return xlmr_encode_impl(h, input_ids, attention_mask, B, L, out);
+    // Two lanes (option dual_stream) as in jg_extract_gesture: sequences are independent, and at B * L = 16 384 tokens the N = 768
+    // GEMMs are single rounds of 192 tiles on 256 CUs and qkv is 2.25 rounds -- two half batches on two streams let one lane's
+    // kernels start on the CUs the other's last round leaves idle.  Per-row results do not depend on the split (tests).
+    auto run_part = [&](int b0, int nb) -> int {
+        h->ws.reset();
+        return xlmr_encode_impl(h, input_ids + (size_t)b0 * L, attention_mask ? attention_mask + (size_t)b0 * L : nullptr, nb, L,
+                                out + (size_t)b0 * L * 768);
+    };
+    return run_in_lanes(h, B, L, run_part, 4);      // equal halves: every token costs the same (measured 3:5 587, 4:4 606 TFLOP/s)
 }
 
 int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {

@@ -122,6 +122,20 @@ struct GemmArgs {
     const signed char* res8;
     signed char* out8;
     int a_tiled;
+    // Implicit LayerNorm (XLM-RoBERTa's post-norm layers, api.hip:xlmr_encode_impl): the token stream holds the UN-normalised rows
+    // x = hi + lo (two fp16 planes; the hi plane is the next GEMM's A operand) and per row (mean, rstd) of x; LN(x) itself is never
+    // materialised.  ln_mode 1 (consumer: the Linear behind the LayerNorm, weights pre-multiplied by gamma):
+    //     out = rstd[m] * (acc - mean[m] * scale[n]) + bias[n]      scale = column sums of the folded weights, bias = b + W beta
+    // ln_mode 2 (producer: the Linear whose output is added to LN(x_prev) and becomes the next x):
+    //     v = acc + bias[n] + scale[n] * rstd[m] * (x_prev[m][n] - mean[m])     scale = gamma, bias = b + beta of that LayerNorm
+    //     out16 / out_lo = hi / lo planes of v (in place over xres_hi / xres_lo is fine), stat_out[m][n / 64] = (sum, sum of squares) of
+    //     the row's 64 columns n .. n + 63 (launch_ln_stats turns them into the next (mean, rstd))
+    int ln_mode;
+    const float* ln_stats;     // [M][2]: (mean, rstd) of the LayerNorm input rows (mode 1: of A's rows; mode 2: of x_prev's rows)
+    const f16* xres_hi;        // mode 2: x_prev planes, row-major [M][ldc]
+    const f16* xres_lo;
+    f16* out_lo;               // mode 2: lo plane of the output
+    float* stat_out;           // mode 2: [M][N / 64][2]
 };
 
 // ---- tiled token stream (N = 512 columns, row tiles of 128) -----------------------------------------------------
@@ -245,11 +259,19 @@ hipError_t launch_segment_mean(const float* seq, int D, const int32_t* seg, int 
 hipError_t launch_fill_f16(f16* p, long n, hipStream_t s);
 hipError_t launch_xlmr_embed(const int32_t* ids, int B, int L, int D, int pad_id, int vocab, int maxpos, const float* word, const float* pos,
                              const float* type, float* out, hipStream_t s);
+// implicit-LayerNorm token stream (GemmArgs::ln_mode): embeddings as un-normalised hi / lo planes + per-64-column (sum, sum of squares)
+hipError_t launch_xlmr_embed_planes(const int32_t* ids, int B, int L, int D, int pad_id, int vocab, int maxpos, const float* word, const float* pos,
+                                    const float* type, f16* hi, f16* lo, float* part, hipStream_t s);
+// part [rows][P][2] (sum, sum of squares per 64-column block, P = D / 64) -> stats [rows][2] = (mean, 1 / sqrt(var_biased + 1e-5))
+hipError_t launch_ln_stats(const float* part, int rows, int P, float* stats, hipStream_t s);
+// out32 = LayerNorm(hi + lo) (nn.LayerNorm, eps 1e-5), D = 768: the explicit LayerNorm at the end of the implicit chain
+hipError_t launch_layernorm_planes(const f16* hi, const f16* lo, const float* w, const float* b, int rows, int D, float* out32, hipStream_t s);
 hipError_t launch_gelu(const float* in, f16* out, long n, hipStream_t s);
 hipError_t launch_mask_i32_f32(const int32_t* in, float* out, long n, hipStream_t s);
 hipError_t launch_broadcast_channels(const f16* v, int C, f16* out, long pixels, hipStream_t s);
 hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* mel_basis, float* out, hipStream_t s);
-hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s);
+// stats != nullptr ([M][2] mean, rstd): sums of the NORMALISED rows (A[m][k] - mean[m]) * rstd[m] (calibration of an implicit-LayerNorm consumer)
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s, const float* stats = nullptr);
 size_t col_sum_scratch_elems(int K);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,

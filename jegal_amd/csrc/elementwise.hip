@@ -501,6 +501,106 @@ hipError_t launch_xlmr_embed(const int32_t* ids, int B, int L, int D, int pad_id
     hipLaunchKernelGGL(xlmr_embed_kernel, dim3((unsigned)(((long)B * L + 3) / 4)), dim3(256), 0, s, ids, B, L, D, pad_id, vocab, maxpos, word, pos, type, out);
     return hipGetLastError();
 }
+// Implicit-LayerNorm token stream (GemmArgs::ln_mode, common.h): the same embedding sum, NOT normalised, as two fp16 planes
+// (hi = fp16(x), lo = fp16(x - hi)) plus per row and 64-column block the (sum, sum of squares) that launch_ln_stats turns into the
+// embedding LayerNorm's (mean, rstd).  One wave per token row; lane l holds columns 256 i + 4 l .. + 3: block = 4 i + l / 16.
+__global__ __launch_bounds__(256) void xlmr_embed_planes_kernel(const int32_t* __restrict__ ids, int B, int L, int D, int pad_id, int vocab, int maxpos,
+                                                                const float* __restrict__ word, const float* __restrict__ pos,
+                                                                const float* __restrict__ type, f16* __restrict__ hi, f16* __restrict__ lo,
+                                                                float* __restrict__ part) {
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (long)B * L) return;
+    const int b = (int)(row / L), t = (int)(row - (long)b * L);
+    int cnt = 0;
+    for (int j = lane; j <= t; j += 64) cnt += ids[(long)b * L + j] != pad_id ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    int id = ids[row];
+    int pid = id != pad_id ? pad_id + cnt : pad_id;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    pid = pid >= maxpos ? maxpos - 1 : pid;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(word + (long)id * D + c);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long)pid * D + c);
+        const f32x4 ty = *reinterpret_cast<const f32x4*>(type + c);
+        const f32x4 v = (w + ty) + p;
+        const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+        const f16x4 l = {(f16)(v.x - (float)h.x), (f16)(v.y - (float)h.y), (f16)(v.z - (float)h.z), (f16)(v.w - (float)h.w)};
+        *reinterpret_cast<f16x4*>(hi + row * D + c) = h;
+        *reinterpret_cast<f16x4*>(lo + row * D + c) = l;
+        float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            s1 += __shfl_xor(s1, d, 64);
+            s2 += __shfl_xor(s2, d, 64);
+        }
+        if ((lane & 15) == 0) *reinterpret_cast<f32x2_t*>(part + 2 * (row * (D >> 6) + (c >> 6))) = f32x2_t{s1, s2};
+    }
+}
+hipError_t launch_xlmr_embed_planes(const int32_t* ids, int B, int L, int D, int pad_id, int vocab, int maxpos, const float* word, const float* pos,
+                                    const float* type, f16* hi, f16* lo, float* part, hipStream_t s) {
+    if (D % 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(xlmr_embed_planes_kernel, dim3((unsigned)(((long)B * L + 3) / 4)), dim3(256), 0, s, ids, B, L, D, pad_id, vocab, maxpos, word, pos, type,
+                       hi, lo, part);
+    return hipGetLastError();
+}
+// (mean, rstd) of every row from its per-block partial sums, accumulated in double: var = E[x^2] - mean^2 (biased, nn.LayerNorm), eps 1e-5
+__global__ void ln_stats_kernel(const float* __restrict__ part, int rows, int P, float* __restrict__ stats) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(part + 2 * ((long)r * P + p));
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    const double inv_d = 1.0 / (double)(P * 64), mean = s1 * inv_d;
+    double var = s2 * inv_d - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    *reinterpret_cast<f32x2_t*>(stats + 2 * (long)r) = f32x2_t{(float)mean, 1.f / sqrtf((float)var + 1e-5f)};
+}
+hipError_t launch_ln_stats(const float* part, int rows, int P, float* stats, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, P, stats);
+    return hipGetLastError();
+}
+// out32 = nn.LayerNorm(hi + lo): the explicit LayerNorm that ends an implicit chain (two-pass statistics like layernorm_kernel)
+template <int V>
+__global__ void layernorm_planes_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, const float* __restrict__ w, const float* __restrict__ b,
+                                        int rows, float* __restrict__ out32) {
+    constexpr int D = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(hi + row * D + (i * 64 + lane) * 4), l = *reinterpret_cast<const f16x4*>(lo + row * D + (i * 64 + lane) * 4);
+        v[i] = f32x4{(float)h.x + (float)l.x, (float)h.y + (float)l.y, (float)h.z + (float)l.z, (float)h.w + (float)l.w};
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) * (1.f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        v[i] -= mean;
+        sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float inv = 1.f / sqrtf(wave_sum(sq) * (1.f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        *reinterpret_cast<f32x4*>(out32 + row * D + col) = v[i] * inv * *reinterpret_cast<const f32x4*>(w + col) + *reinterpret_cast<const f32x4*>(b + col);
+    }
+}
+hipError_t launch_layernorm_planes(const f16* hi, const f16* lo, const float* w, const float* b, int rows, int D, float* out32, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (D != 768) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_planes_kernel<3>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, hi, lo, w, b, rows, out32);
+    return hipGetLastError();
+}
 // exact GELU (erf form, the HF "gelu"): fp32 in -> fp16 out
 __global__ void gelu_kernel(const float* __restrict__ in, f16* __restrict__ out, long n4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -565,14 +665,16 @@ hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int
 // Deterministic (no atomics): 64 row-strided partial sums per column go to `part` [gy][K], then one thread per column
 // adds them to out[] in a fixed order.  out ACCUMULATES across calls (stream order), so a calibration batch may arrive
 // in chunks and two handles calibrated on the same data end up with bit-identical bias corrections.
-__global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K, float* __restrict__ part) {
+// stats ([M][2] mean, rstd; optional): the rows are normalised first -- what a Linear behind an IMPLICIT LayerNorm effectively sees.
+__global__ void col_sum_kernel(const f16* __restrict__ A, long lda, int M, int K, float* __restrict__ part, const float* __restrict__ stats) {
     const int c8 = blockIdx.x * blockDim.x + threadIdx.x;
     if (c8 * 8 >= K) return;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int m = blockIdx.y; m < M; m += gridDim.y) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(A + (long)m * lda + c8 * 8);
+        const float mu = stats ? stats[2 * (long)m] : 0.f, rs = stats ? stats[2 * (long)m + 1] : 1.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        for (int e = 0; e < 8; ++e) acc[e] += ((float)v[e] - mu) * rs;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[(long)blockIdx.y * K + c8 * 8 + e] = acc[e];
@@ -587,11 +689,11 @@ __global__ void col_sum_finish_kernel(const float* __restrict__ part, int gy, in
 
 size_t col_sum_scratch_elems(int K) { return (size_t)64 * K; }
 
-hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s) {
+hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s, const float* stats) {
     if (M <= 0 || K <= 0) return hipSuccess;
     const int cols = K / 8;
     const int gy = M < 64 ? M : 64;
-    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, scratch);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((cols + 63) / 64, gy), dim3(64), 0, s, A, lda, M, K, scratch, stats);
     hipLaunchKernelGGL(col_sum_finish_kernel, dim3((K + 255) / 256), dim3(256), 0, s, scratch, gy, K, out);
     return hipGetLastError();
 }

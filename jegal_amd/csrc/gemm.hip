@@ -222,10 +222,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // SPR: plain GEMM -- the next k-tile's DMA pieces are spread over the MFMA schedule (K <= 1024 instances);
 //      CONV -- the loader can read the producer's left-out leading rows from a const image (ConvGeom::in_op / const_in).
 // Every CONV instance honours ConvGeom::rowmap on its output side (compacted row index, row_full()).
-template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false>
+// XE:  plain GEMM instances that also know the implicit-LayerNorm epilogues (GemmArgs::ln_mode, common.h) -- their own
+//      instantiations, so that the epilogue code and its registers never reach the instances of the gesture path.
+//      XE = 1: consumer (ln_mode 1), XE = 2: producer (ln_mode 2); each is compiled with that one epilogue only (no residual, no
+//      tiled operand, no generic path: launch_gemm checks the shapes), which is what keeps the 256x256 instance free of spills.
+template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false, int XE = 0>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
     static_assert(!LNF || (WM == 1 && !W2), "fused LayerNorm needs a row-wide tile: all 8 waves side by side along n");
+    static_assert(!XE || (!CONV && !LNF), "implicit-LayerNorm epilogues: plain GEMM instances only");
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr int XI = BM / 64, WI = BN / 64;            // LDS-DMA instructions (8 rows each) per wave per k-tile
     constexpr int XB = BM * 128, WB = BN * 128;
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 if constexpr (ROWCONST) xalt[i] = a.g.const_in + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
             } else {
                 xpix[i] = 0;
-                xsrc[i] = a.a_tiled ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) * 1024 + (m & 15) * 16 + (c >> 1) * 256 + (c & 1) * 8
-                                    : a.A + (long)m * a.lda + c * 8;
+xsrc[i] = (!XE && a.a_tiled) ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) * 1024 + (m & 15) * 16 + (c >> 1) * 256 + (c & 1) * 8
+                                            : a.A + (long)m * a.lda + c * 8;
             }
         }
         // N % BN == 0 (launch_gemm sends anything else to gemm_kernel): no row clamp, piece i = base[i & 1] + (i >> 1) * 16 rows
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 src = ok ? xsrc[i] + stapoff : zeros;
                 if (ROWCONST && ok && ih < (xpix[i] & 0xff)) src = xalt[i] + stapoff;
             } else {
-                src = xsrc[i] + (a.a_tiled ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
+src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // tiled plane: a k-tile is 8192 elements on
             }
             // LNF, long K (linear2: 413 MB of hidden activations read once by one tile each): nontemporal (aux = 2) so
             // the stream does not push the weights out of L2.  Measured: linear2+LN 282 -> 266 us; for out_proj (K = 512,
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     const int nk = (a.K + 63) / 64;
     // conv launches carry no residual (launch_gemm rejects them): the conv instances are compiled without that path -- the
     // hoisted reciprocal of its `m % res_mod` alone cost the 512x128 instance a spilled register
-    const float* const ares = CONV ? nullptr : a.res;
+    const float* const ares = (CONV || XE) ? nullptr : a.res;
 
     int round = 0;
     int bid = tile_of(0);
@@ -582,6 +587,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         constexpr int TP16 = 144;                        // row pitch: 16-B aligned, 36 banks -> conflict-free b64 writes
         constexpr bool ROWS_OK = STAGE / 8 >= 16 * TP16;
         const bool rows16 = ROWS_OK && interior && a.out16 && !a.out32 && !ares && (a.ldc & 7) == 0;
+        // implicit LayerNorm (XE instances; launch_gemm checks the shapes): 1 = consumer, through the rows16 path with per-row
+        // (rstd, mean) factors; 2 = producer, the two-plane path below
+        constexpr int xmode = XE;
         const int orow_m = cm0 + wm * (16 * MI) + (lane >> 3);
         // ConvGeom::rowmap: the full output rows of this wave's 16*MI tile rows (both store paths below stay inside them) go
         // through a per-wave table in LDS -- 1-2 loads per lane, in front of the next tile's setup and OLDER than its first DMA,
@@ -723,7 +731,102 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         // whole k loop at K = 512 (tools/store_pattern.hip, tools/gemm_timeline.py).  The scratch is this wave's
         // slice of LDS stage 1, idle until the next tile's k-tile 1 is staged (after the barrier at the loop top);
         // a wave's LDS instructions execute in order, so consecutive 16-row blocks reuse the same 2.3 KB.
-        if (rows16) {
+        constexpr bool xdone = XE == 2;
+        if constexpr (XE == 2) {
+            {
+                // ---- implicit-LayerNorm producer: v = acc + bias + gamma * rstd[m] * (x_prev - mean[m]); v leaves as two fp16 planes
+                // (hi = fp16(v), the next GEMM's A operand; lo = fp16(v - hi)) through the row-transposing scratch, one plane after
+                // the other, plus the (sum, sum of squares) of this wave's 64 columns per row.  The residual planes are read in
+                // fragment order (4 x 8 B per plane and 16-row block: one 128-B line per row over the four i), one block ahead.
+                // registers (the 256x256 instance holds 128 accumulators): the bias goes into the accumulators up front, the row
+                // statistics ride with the residual prefetch, and where LDS stage 1 has room for two scratch areas per wave the lo plane
+                // is written to its own area next to the hi plane instead of waiting in registers
+                constexpr bool LO_LDS = STAGE / 8 >= 32 * TP16;
+                char* tsc = smem + STAGE + wave * ((LO_LDS ? 32 : 16) * TP16);
+                char* tsl = LO_LDS ? tsc + 16 * TP16 : tsc;
+                // gamma of this wave's 64 columns waits in LDS (256 B behind the transposing scratch; one ds_read_b128 per use)
+                float* gsc = reinterpret_cast<float*>(smem + STAGE + 8 * ((LO_LDS ? 32 : 16) * TP16)) + wave * 64;
+                static_assert(STAGE >= 8 * ((LO_LDS ? 32 : 16) * TP16) + 8 * 256, "LDS stage 1 holds the epilogue scratch");
+                gsc[lane] = a.scale[cn0 + wn * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 bi = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) acc[i][j] += bi;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f16x4 rh[2][4], rl[2][4];
+                f32x2_t rst[2];
+                auto ldres = [&](int j) __attribute__((always_inline)) {
+                    const int m = mb + j * 16 < Mrows ? mb + j * 16 : Mrows - 1;
+                    const long o = (long)m * a.ldc + nb;
+                    rst[j & 1] = *reinterpret_cast<const f32x2_t*>(a.ln_stats + 2 * (long)m);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        rh[j & 1][i] = *reinterpret_cast<const f16x4*>(a.xres_hi + o + i * 16);
+                        rl[j & 1][i] = *reinterpret_cast<const f16x4*>(a.xres_lo + o + i * 16);
+                    }
+                };
+                ldres(0);
+                const long ocol = cn0 + wn * 64 + (lane & 7) * 8;
+                const int sblk = (cn0 >> 6) + wn, nblk = a.N >> 6;
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    if (j + 1 < MI) ldres(j + 1);
+                    float s1 = 0.f, s2 = 0.f;
+                    f16x4 lo4[LO_LDS ? 1 : 4];
+                    const float mu = rst[j & 1].x, rs = rst[j & 1].y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f16x4 xh = rh[j & 1][i], xl = rl[j & 1][i];
+                        const f32x4 x = {(float)xh.x + (float)xl.x, (float)xh.y + (float)xl.y, (float)xh.z + (float)xl.z, (float)xh.w + (float)xl.w};
+                        const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(gsc + i * 16 + fq * 4) * ((x - mu) * rs);
+                        s1 += (v.x + v.y) + (v.z + v.w);
+                        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                        const f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                        const f16x4 lv = {(f16)(v.x - (float)hv.x), (f16)(v.y - (float)hv.y), (f16)(v.z - (float)hv.z), (f16)(v.w - (float)hv.w)};
+                        *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
+                        if (LO_LDS) *reinterpret_cast<f16x4*>(tsl + frow * TP16 + i * 32 + fq * 8) = lv;
+                        else lo4[i] = lv;
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        if (pl == 1 && LO_LDS) break;
+                        if (pl == 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = lo4[LO_LDS ? 0 : i];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                        for (int q2 = 0; q2 < (LO_LDS ? 2 : 1); ++q2) {
+                            f16* const plane = (LO_LDS ? q2 : pl) ? a.out_lo : a.out16;
+                            const char* src = (LO_LDS && q2) ? tsl : tsc;
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const f16x8 o = *reinterpret_cast<const f16x8*>(src + (h2 * 8 + (lane >> 3)) * TP16 + (lane & 7) * 16);
+                                const long orow = orow_m + j * 16 + h2 * 8;
+                                if (m_full || orow < Mrows) *reinterpret_cast<f16x8*>(plane + orow * a.ldc + ocol) = o;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (fq == 0 && (m_full || mb + j * 16 < Mrows))
+                        *reinterpret_cast<f32x2_t*>(a.stat_out + 2 * ((long)(mb + j * 16) * nblk + sblk)) = f32x2_t{s1, s2};
+                }
+            }
+        }
+        if constexpr (xdone) {
+        } else if (rows16 || XE == 1) {
             char* tsc = smem + STAGE + wave * (16 * TP16);
             f32x4 sc[4], bi[4];
 #pragma unroll
@@ -731,7 +834,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 sc[i] = f32x4{1.f, 1.f, 1.f, 1.f};
                 bi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (a.scale) {
+            if (XE != 1 && a.scale) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
             }
@@ -740,13 +843,35 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
             }
             f16* ocol = a.out16 + cn0 + wn * 64 + (lane & 7) * 8;
+            // ln_mode 1: out = rstd[m] * (acc - mean[m] * c1[n]) + bias[n], c1 (column sums of the folded weights) in `sc`
+            float xrs[XE ? MI : 1], xrm[XE ? MI : 1];
+            // (registers: c1 of this wave's 64 columns waits in LDS behind the transposing scratch instead of in `sc`)
+            float* gsc = reinterpret_cast<float*>(smem + STAGE + 8 * (16 * TP16)) + wave * 64;
+            if constexpr (XE == 1) {
+                static_assert(!XE || STAGE >= 8 * (16 * TP16) + 8 * 256, "LDS stage 1 holds the epilogue scratch");
+                gsc[lane] = a.scale[cn0 + wn * 64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) {
+                        const int m = mb + j * 16 < Mrows ? mb + j * 16 : Mrows - 1;
+                        const f32x2_t st = *reinterpret_cast<const f32x2_t*>(a.ln_stats + 2 * (long)m);
+                        xrs[j] = st.y;
+                        xrm[j] = st.x * st.y;
+                    }
+                }
+            }
             auto store_rows = [&](auto masked_tag) __attribute__((always_inline)) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        f32x4 v = acc[i][j] * sc[i] + bi[i];
+                        f32x4 v;
+                        if constexpr (XE == 1) v = acc[i][j] * xrs[XE ? j : 0] + (bi[i] - *reinterpret_cast<const f32x4*>(gsc + i * 16 + fq * 4) * xrm[XE ? j : 0]);
+                        else v = acc[i][j] * sc[i] + bi[i];
                         v = act4(v, CONV ? (a.relu != 0) : a.relu);
                         f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
                         *reinterpret_cast<f16x4*>(tsc + frow * TP16 + i * 32 + fq * 8) = hv;
@@ -766,6 +891,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 }
             };
             if (m_full) store_rows(std::false_type{}); else store_rows(std::true_type{});
+        } else if constexpr (XE != 0) {
         } else if (interior) {
             f32x4 sc[4], bi[4];
 #pragma unroll
@@ -841,7 +967,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
         }
         mark();     // 3: epilogue issued
         if (nbid < 0) break;
-        pending = !(interior && m_full && counted_ok) ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
+        pending = !(interior && m_full && counted_ok) || xdone ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
     }
 }
 
@@ -901,12 +1027,12 @@ static hipError_t ensure_lds_attr(K kernel, size_t lds, int device, bool* flags)
     return hipSuccess;
 }
 
-template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false>
+template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false, int XE = 0>
 static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[MAX_DEV] = {};
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr size_t lds = 2 * (size_t)(BM * 128 + BN * 128 * (W2 ? 2 : 1));
-    hipError_t e = ensure_lds_attr(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>, lds, o.device, attr_set);
+    hipError_t e = ensure_lds_attr(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE>, lds, o.device, attr_set);
     if (e != hipSuccess) return e;
     if (!o.zeros) return hipErrorInvalidValue;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
@@ -927,7 +1053,7 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStr
     const int last_round = tiles % o.num_cu;
     const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger
                         : (!CONV && !o.lanes_active && tiles > o.num_cu && 2 * last_round < o.num_cu ? 300 : 0);
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
                        o.gemm_counted | (stagger << 8), o.gemm_tl);
     if (o.gemm_tl) dump_timeline(o, s, CONV ? "conv" : "linear");
     return hipGetLastError();
@@ -992,6 +1118,24 @@ static hipError_t launch_glds(const GemmArgs& a, const EngineOpts& o, hipStream_
             const long tiles = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
             return (double)((tiles + o.num_cu - 1) / o.num_cu) * (nk * kt_us + epi_us);
         };
+        if (a.ln_mode) {
+            // implicit-LayerNorm epilogues (XE instances): single fp16 weights -> 256x256 or 128x128, hi+lo -> 256x128 or 128x128, by the
+            // same cost estimate
+            auto go = [&](auto xe) -> hipError_t {
+                constexpr int X = decltype(xe)::value;
+                if constexpr (W2) {
+                    if (est(128, 128, 1.25, 1.0) < est(256, 128, 1.6, 1.6) && o.gemm_tile != 2) return launch_glds_cfg<true, false, 2, 4, 2, false, X>(a, o, s);
+                    return launch_glds_cfg<true, false, 4, 4, 2, false, X>(a, o, s);
+                } else {
+                    const bool big_ok = a.N % 256 == 0;
+                    if (!big_ok || (est(128, 128, 0.95, 1.0) < est(256, 256, 1.45, 2.7) && o.gemm_tile != 3) || o.gemm_tile == 1)
+                        return launch_glds_cfg<false, false, 2, 4, 2, false, X>(a, o, s);
+                    if (a.K <= 1024) return launch_glds_cfg<false, false, 8, 2, 4, true, X>(a, o, s);
+                    return launch_glds_cfg<false, false, 8, 2, 4, false, X>(a, o, s);
+                }
+            };
+            return a.ln_mode == 1 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 2>{});
+        }
         const bool can_big = !W2 && o.gemm_big_tile && a.N >= 256 && a.N % 256 == 0;
         const double e_small = o.gemm_small_tile ? est(128, 128, W2 ? 1.25 : 0.95, 1.0) : 1e30;
         const double e_mid = est(256, 128, W2 ? 1.6 : 1.2, 1.6);
@@ -1039,6 +1183,16 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStr
     }
     const bool w2 = a.Wl != nullptr;
     const bool narrow = a.N <= 64;
+    if (a.ln_mode) {
+        // implicit LayerNorm: LDS-DMA instances with the fast epilogues only (whole tiles along n, 16-byte rows); anything else is a
+        // caller error -- there is no slow path that would quietly ignore the statistics
+        const bool shape_ok = !conv && o.gemm_glds && a.K % 64 == 0 && a.M >= 128 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.N % 128 == 0 && a.ldc % 8 == 0;
+        const bool mode1_ok = a.ln_mode == 1 && a.ln_stats && a.scale && a.bias && a.out16 && !a.out32 && !a.res;
+        const bool mode2_ok = a.ln_mode == 2 && a.ln_stats && a.scale && a.bias && a.out16 && a.out_lo && a.xres_hi && a.xres_lo && a.stat_out &&
+                              !a.out32 && !a.res && !a.relu;
+        if (!shape_ok || !(mode1_ok || mode2_ok) || a.ln_w || a.a_tiled) return hipErrorInvalidValue;
+        return w2 ? launch_glds<true, false>(a, o, s) : launch_glds<false, false>(a, o, s);
+    }
     if (a.a_tiled && (conv || narrow || !o.gemm_glds || a.K != 512 || a.M < 128 || a.N % 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
     if (conv) {
         if (a.res) return hipErrorInvalidValue;          // the conv instances are compiled without the residual path
