@@ -166,9 +166,11 @@ struct jg_handle {
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
     bool dual_stream = true;
     int dual_split = 3;            // the first lane gets dual_split/8 of the batch
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
-    Arena lane_ws[2];
-    hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};      // [0]: the caller's stream at entry, [1], [2]: end of each lane
+    static constexpr int MAX_LANES = 4;
+    hipStream_t lane_stream[MAX_LANES] = {};
+    Arena lane_ws[MAX_LANES];
+    hipEvent_t lane_ev[MAX_LANES + 1] = {};      // [0]: the caller's stream at entry, [1 + l]: end of lane l
+    int xl_lanes = 2;              // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams
 };
 
 namespace {
@@ -1353,29 +1355,34 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     return gemm(h, JG_ST_GEMM, a16, 512, rows, h->al_c2, o);
 }
 
-// Run a batch of B clips as two parts on the two lane streams (option "dual_stream", jg_handle::lane_*): run_part(b0, nb) enqueues
-// one part on h->stream / h->ws, which are the current lane's while it is called.  Entry: both lane streams wait for the caller's
-// stream; exit: the caller's stream waits for both lanes.  Small batches run as one part on the caller's stream.
+// Run a batch of B independent items (clips, token sequences) as parts on the lane streams (option "dual_stream", jg_handle::lane_*):
+// run_part(b0, nb) enqueues one part on h->stream / h->ws, which are the current lane's while it is called.  Entry: the lane streams
+// wait for the caller's stream; exit: the caller's stream waits for every lane.  Small batches run as one part on the caller's stream.
 template <class F>
-int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int split = 0) {
-    const int sp = split ? split : h->dual_split;        // eighths of the batch on the first lane
+int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int equal_lanes = 0) {
+    // equal_lanes = 0: two lanes, the first gets dual_split eighths of the batch (the gesture path); n > 0: n equal parts.
     // (small parts would fall below the LDS-DMA GEMM's 128-row minimum in the JEGAL branch and take the register-staged kernel,
-    // whose summation order differs in the last bit: keep both parts in the regime of the whole batch)
-    if (!h->dual_stream || h->calib || B < 8 || (long)((B * sp + 4) / 8) * T < 256) return run_part(0, B);
-    for (int l = 0; l < 2; ++l)
+    // whose summation order differs in the last bit: keep every part in the regime of the whole batch)
+    const int nl = equal_lanes ? equal_lanes : 2;
+    int start[jg_handle::MAX_LANES + 1];
+    start[0] = 0;
+    for (int l = 1; l <= nl; ++l) start[l] = equal_lanes ? (int)((long)B * l / nl) : (l == 1 ? (B * h->dual_split + 4) / 8 : B);
+    int smallest = B;
+    for (int l = 0; l < nl; ++l) smallest = std::min(smallest, start[l + 1] - start[l]);
+    if (!h->dual_stream || h->calib || nl < 2 || B < 8 || (long)smallest * T < 256) return run_part(0, B);
+    for (int l = 0; l < nl; ++l)
         if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
-    for (int e = 0; e < 3; ++e)
+    for (int e = 0; e < nl + 1; ++e)
         if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
     hipStream_t user = h->stream;
     HIPCHK(h, hipEventRecord(h->lane_ev[0], user));
-    const int B0 = (B * sp + 4) / 8;
     int rc = JG_OK;
-    for (int l = 0; l < 2 && rc == JG_OK; ++l) {
+    for (int l = 0; l < nl && rc == JG_OK; ++l) {
         if (hipStreamWaitEvent(h->lane_stream[l], h->lane_ev[0], 0) != hipSuccess) { rc = JG_ERR_HIP; break; }
         h->stream = h->lane_stream[l];
         std::swap(h->ws, h->lane_ws[l]);
         h->opts.lanes_active = true;
-        rc = l == 0 ? run_part(0, B0) : run_part(B0, B - B0);
+        rc = run_part(start[l], start[l + 1] - start[l]);
         h->opts.lanes_active = false;
         std::swap(h->ws, h->lane_ws[l]);
         h->stream = user;
@@ -1432,8 +1439,8 @@ int jg_destroy(jg_handle* h) {
         if (h->feats) hipFree(h->feats);
         if (h->gs_qpe) hipFree(h->gs_qpe);
         h->ws.release();
-        for (int l = 0; l < 2; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]); }
-        for (int e = 0; e < 3; ++e) if (h->lane_ev[e]) hipEventDestroy(h->lane_ev[e]);
+        for (int l = 0; l < jg_handle::MAX_LANES; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]); }
+        for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
         if (h->own_stream) hipStreamDestroy(h->own_stream);
     }
@@ -1475,6 +1482,11 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "xlmr_lanes")) {
+        if (value < 1 || value > jg_handle::MAX_LANES) JG_FAIL(h, JG_ERR_ARG, "xlmr_lanes must be 1..%d", jg_handle::MAX_LANES);
+        h->xl_lanes = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "xlmr_fold")) { h->xl_fold_opt = value != 0; return JG_OK; }       // takes effect at the next jg_finalize_weights(h, 4)
     if (!std::strcmp(name, "dual_split")) {
         if (value < 1 || value > 7) JG_FAIL(h, JG_ERR_ARG, "dual_split must be 1..7 (eighths of the batch on the first lane)");
@@ -1744,7 +1756,7 @@ int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attent
         return xlmr_encode_impl(h, input_ids + (size_t)b0 * L, attention_mask ? attention_mask + (size_t)b0 * L : nullptr, nb, L,
                                 out + (size_t)b0 * L * 768);
     };
-    return run_in_lanes(h, B, L, run_part, 4);      // equal halves: every token costs the same (measured 3:5 587, 4:4 606 TFLOP/s)
+    return run_in_lanes(h, B, L, run_part, h->xl_lanes);      // equal parts: every token costs the same (two lanes: 3:5 587, 4:4 606 TFLOP/s)
 }
 
 int jg_word_pool(jg_handle* h, const float* seq, int D, const int32_t* seg, int n, float* dst, int dst_ld, int dst_col) {
@@ -1858,6 +1870,11 @@ int jg_profile_reset(jg_handle* h) {
     return JG_OK;
 }
 
-int64_t jg_workspace_bytes(jg_handle* h) { return h ? (int64_t)(h->ws.total() + h->lane_ws[0].total() + h->lane_ws[1].total()) : 0; }
+int64_t jg_workspace_bytes(jg_handle* h) {
+    if (!h) return 0;
+    size_t t = h->ws.total();
+    for (int l = 0; l < jg_handle::MAX_LANES; ++l) t += h->lane_ws[l].total();
+    return (int64_t)t;
+}
 
 }  // extern "C"

@@ -73,6 +73,41 @@ def test_xlmr_properties_and_errors(xlmr):
         xlmr(np.ones((1, 600), np.int32))                             # beyond the position table
 
 
+def test_xlmr_implicit_layernorm_and_lanes(xlmr):
+    """Round 4: the default pass never materialises a LayerNorm (option xlmr_fold: un-normalised hi + lo token planes, LayerNorm
+    folded into the consumer GEMMs / recomputed in the producer epilogues, api.hip:xlmr_encode_folded) and runs a batch as two
+    half batches on two streams.  Both against the explicit-LayerNorm pass (xlmr_fold=0) and the fp32 restatement; the lanes
+    must not change a bit; hi+lo (default) and single-fp16 (calibrated) weights alike."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.xlmr import XLMRoberta
+    sd = synth.xlmr_state_dict()
+    ids, mask = synth.xlmr_inputs(31, 16, 40)                         # ragged padding; 2 x 320 rows: both lanes above the 256-row minimum
+    with torch.no_grad():
+        ref = O.xlmr_forward(sd, ids, mask)
+    m = torch.from_numpy(mask).bool()
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    eng0 = Engine(0)
+    eng0.set_option("xlmr_fold", 0)
+    plain = XLMRoberta(engine=eng0).load_state_dict(sd)
+    try:
+        for calibrated in (False, True):
+            if calibrated:
+                xlmr.calibrate(ids_d[:4], mask_d[:4])
+                plain.calibrate(ids_d[:4], mask_d[:4])
+            a = xlmr(ids_d, attention_mask=mask_d).last_hidden_state
+            xlmr.engine.set_option("dual_stream", 0)
+            b = xlmr(ids_d, attention_mask=mask_d).last_hidden_state
+            xlmr.engine.set_option("dual_stream", 1)
+            assert torch.equal(a, b)
+            c = plain(ids_d, attention_mask=mask_d).last_hidden_state
+            ea, ec, eac = rel(a.cpu()[m], ref[m]), rel(c.cpu()[m], ref[m]), rel(a.cpu()[m], c.cpu()[m])
+            print(f"calibrated={calibrated}: implicit LN vs oracle {ea:.3e}, explicit LN vs oracle {ec:.3e}, implicit vs explicit {eac:.3e}")
+            assert ea < TOL and ec < TOL and eac < TOL
+    finally:
+        eng0.close()
+        xlmr.load_state_dict({"roberta." + k: v for k, v in sd.items()})          # back to the un-calibrated weights for the tests below
+
+
 class StubTokenizer:
     """HuggingFace-fast-tokenizer calling convention (is_split_into_words, offsets, padding) over a toy vocabulary: every word
     becomes one or two sub-word ids; <s> = 0, </s> = 2, <pad> = 1 as in xlm-roberta (the real sentencepiece model is not
