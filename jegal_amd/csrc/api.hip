@@ -166,6 +166,7 @@ struct jg_handle {
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
     bool dual_stream = true;
     int dual_split = 3;            // the first lane gets dual_split/8 of the batch
+    std::map<hipStream_t, Arena> ws_parked;      // arenas of the other streams this handle has been bound to (jg_set_stream)
     static constexpr int MAX_LANES = 4;
     hipStream_t lane_stream[MAX_LANES] = {};
     Arena lane_ws[MAX_LANES];
@@ -1439,6 +1440,7 @@ int jg_destroy(jg_handle* h) {
         if (h->feats) hipFree(h->feats);
         if (h->gs_qpe) hipFree(h->gs_qpe);
         h->ws.release();
+        for (auto& kv : h->ws_parked) kv.second.release();
         for (int l = 0; l < jg_handle::MAX_LANES; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]); }
         for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
@@ -1449,9 +1451,23 @@ int jg_destroy(jg_handle* h) {
 }
 const char* jg_last_error(jg_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
+// The workspace arena is stream-ordered (every entry point resets and re-uses it), so it belongs to ONE stream: a handle that is
+// driven from several streams -- e.g. JEGAL.forward_inference runs the content path on a side stream beside the gesture encoder --
+// keeps one arena per stream and switches with the stream.  (Before round 4 two calls on two un-synchronised streams shared one arena.)
 int jg_set_stream(jg_handle* h, void* s) {
     if (!h) return JG_ERR_ARG;
-    h->stream = reinterpret_cast<hipStream_t>(s);   // NULL is the legacy default stream, used as such
+    hipStream_t ns = reinterpret_cast<hipStream_t>(s);   // NULL is the legacy default stream, used as such
+    if (ns != h->stream) {
+        std::swap(h->ws, h->ws_parked[h->stream]);       // park the current arena under its stream ...
+        std::swap(h->ws, h->ws_parked[ns]);              // ... and take the new stream's (empty the first time)
+        h->ws_parked.erase(ns);
+        if (h->ws_parked.size() > 6) {                   // a caller cycling through many streams: drop the parked arenas (hipFree waits for the device)
+            DeviceGuard dg(h->device);
+            for (auto& kv : h->ws_parked) kv.second.release();
+            h->ws_parked.clear();
+        }
+        h->stream = ns;
+    }
     return JG_OK;
 }
 
@@ -1874,6 +1890,7 @@ int64_t jg_workspace_bytes(jg_handle* h) {
     if (!h) return 0;
     size_t t = h->ws.total();
     for (int l = 0; l < jg_handle::MAX_LANES; ++l) t += h->lane_ws[l].total();
+    for (auto& kv : h->ws_parked) t += kv.second.total();
     return (int64_t)t;
 }
 

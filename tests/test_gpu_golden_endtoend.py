@@ -192,6 +192,26 @@ def test_jegal_vta_golden(models, golden_dir):
                                   audio_mask=torch.ones(2, 40), word_boundaries=wb2)
     assert rel(ge, g["gesture"]) < TOL
     assert rel(ce, g["content"]) < TOL
+    # round 4: the engine keeps one workspace arena per stream (jg_set_stream).  Two callers on two un-synchronised streams, their
+    # calls interleaved call by call, must get what each gets alone (before, the second call re-used the arena the first one's
+    # kernels were still working in).
+    vf2 = torch.flip(vf, dims=[1]).contiguous().cuda()
+    ge_b, ce_b = jg.forward_inference(visual_feats=vf2, visual_mask=vm.cuda(), text=_text_pack(gt), audio=mel * 0.5 + 4.0,
+                                      audio_mask=torch.ones(2, 40), word_boundaries=wb2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            o1 = jg.forward_inference(visual_feats=vf.cuda(), visual_mask=vm.cuda(), text=_text_pack(gt), audio=mel,
+                                      audio_mask=torch.ones(2, 40), word_boundaries=wb2)
+        with torch.cuda.stream(s2):
+            o2 = jg.forward_inference(visual_feats=vf2, visual_mask=vm.cuda(), text=_text_pack(gt), audio=mel * 0.5 + 4.0,
+                                      audio_mask=torch.ones(2, 40), word_boundaries=wb2)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1[0], ge) and torch.equal(o1[1], ce) and torch.equal(o2[0], ge_b) and torch.equal(o2[1], ce_b)
 
 
 def test_error_behaviour(models):
