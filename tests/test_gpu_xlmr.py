@@ -108,6 +108,27 @@ def test_xlmr_implicit_layernorm_and_lanes(xlmr):
         xlmr.load_state_dict({"roberta." + k: v for k, v in sd.items()})          # back to the un-calibrated weights for the tests below
 
 
+@pytest.mark.parametrize("mode,bound", [("PREC_FP16", 2e-3), ("PREC_FP16_W2", 1e-3), ("PREC_BF16", 3e-2)])
+def test_xlmr_other_precision_modes_run_the_implicit_layernorm_path(mode, bound):
+    """The implicit-LayerNorm GEMM instances exist in every build (single fp16, hi+lo, the bf16 re-build with bf16 token planes): plain
+    fp16 and bf16 are reported modes (outside the 1e-3 contract), W2 meets it."""
+    import jegal_amd._lib as L
+    from jegal_amd.xlmr import XLMRoberta
+    sd = synth.xlmr_state_dict()
+    ids, mask = synth.xlmr_inputs(41, 6, 50)
+    with torch.no_grad():
+        ref = O.xlmr_forward(sd, ids, mask)
+    eng = L.Engine(0, precision=getattr(L, mode))
+    try:
+        out = XLMRoberta(engine=eng).load_state_dict(sd)(torch.from_numpy(ids).cuda(), attention_mask=torch.from_numpy(mask).cuda()).last_hidden_state.cpu()
+    finally:
+        eng.close()
+    m = torch.from_numpy(mask).bool()
+    e = rel(out[m], ref[m])
+    print(f"{mode}: XLM-R (implicit LayerNorm) vs the fp32 restatement: rel-L2 {e:.3e}")
+    assert torch.isfinite(out).all() and e < bound
+
+
 class StubTokenizer:
     """HuggingFace-fast-tokenizer calling convention (is_split_into_words, offsets, padding) over a toy vocabulary: every word
     becomes one or two sub-word ids; <s> = 0, </s> = 2, <pad> = 1 as in xlm-roberta (the real sentencepiece model is not
