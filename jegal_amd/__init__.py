@@ -4,6 +4,15 @@ Public surface mirrors the reference's hot-path interface: ``GestSync`` (models/
 ``JEGAL`` (models/jegal.py), metric functions (evaluation/evaluate_*.py).  Nothing here falls back
 to PyTorch math: without libjegal_hip.so and a HIP device the engine raises.
 """
+import os as _os
+
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue
+# serialise.  A streaming caller has more than four: H2D, D2H and compute streams plus the engine's two internal lanes -- measured on
+# MI355X (tools/stream_timeline.py): with an unlucky assignment the upload of batch k+1 queues behind the compute of batch k and
+# GestureStreamer drops from 2 150 to 1 230 clips/s.  Read by the runtime when it initialises, i.e. at the first HIP call: this
+# default only takes effect when jegal_amd is imported before that, and never overrides the caller's own setting.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __all__ = ["GestSync", "JEGAL", "XLMRoberta", "Engine"]
 
 
