@@ -504,7 +504,7 @@ def main():
                 assert np.array_equal(emb_m, out.cpu().numpy()), "masked upload differs from the resident path"
                 del st
                 # source-resolution upload: the decoder's 228x314 frames (reference samples/sample1.avi, inference_embs.py:255-276
-                # resizes them to 270x480 on the host) with their mask rows; mask + resize run on the upload stream (jg_mask_resize_packed)
+                # resizes them to 270x480 on the host) with their mask rows; mask + resize run on the device in front of the batch's compute (jg_mask_resize_packed)
                 SH, SW = 228, 314
                 rng_s = np.random.default_rng(4321)
                 src = rng_s.integers(0, 256, (args.clips, FRAMES, SH, SW, 3), dtype=np.uint8)
@@ -624,14 +624,14 @@ def main():
                 res["pcie_inclusive"]["masked_upload"] = {
                     "value": extras["pcie_masked_clips_per_s"], "unit": "clips/s", "bytes_per_batch": extras["pcie_masked_bytes"],
                     "bytes_per_batch_dense": args.clips * FRAMES * 270 * 480 * 3, "equals_resident_path": True,
-                    "what": "only the rows below each clip's face mask cross the link (GestureStreamer(masked=True)), jg_unpack_masked rebuilds the batch on the upload stream"}
+                    "what": "only the rows below each clip's face mask cross the link (GestureStreamer(masked=True)), jg_unpack_masked rebuilds the batch on the device"}
             if "pcie_source_clips_per_s" in extras:
                 res["pcie_inclusive"]["source_res"] = {
                     "value": extras["pcie_source_clips_per_s"], "unit": "clips/s", "source_hw": extras["pcie_source_hw"],
                     "bytes_per_batch": extras["pcie_source_bytes"], "bytes_per_batch_dense": args.clips * FRAMES * 270 * 480 * 3,
                     "equals_resident_path": True,
                     "what": "decoder-resolution frames (228x314 as in the reference's samples/sample1.avi), only the source rows below each frame's mask "
-                            "cross the link (GestureStreamer(source_hw=...)); face mask + cv2-style bilinear resize to 270x480 on the upload stream "
+                            "cross the link (GestureStreamer(source_hw=...)); face mask + cv2-style bilinear resize to 270x480 on the device "
                             "(jg_mask_resize_packed); bit-identical to load_rgb_masked_frames + the resident path"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(frames_host[:2])

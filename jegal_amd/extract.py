@@ -195,13 +195,13 @@ class GestureStreamer:
 
     ``masked=True`` ships fewer bytes: the reference blanks rows 0..y2+15 of every crop (inference_embs.py:264-270), the
     producer knows y2, so only the rows below each frame's mask cross the host link (``run(clips, mask_rows)`` /
-    ``run_filled`` with a packer) and ``jg_unpack_masked`` rebuilds the dense batch on the device, on the upload stream.
+    ``run_filled`` with a packer) and ``jg_unpack_masked`` rebuilds the dense batch on the device, in front of the batch's compute.
     Bit-identical to uploading the blanked crops whole.
 
     ``source_hw=(H, W)`` ships the DECODER's frames: the reference resizes its 228x314 / 294x294 crops up to 270x480 on the host
     (inference_embs.py:255-276), which is up to 1.8x more bytes than the decoder produced.  Clips are (T,H,W,3) uint8 source
     frames, ``mask_rows`` gives mask_y = y2+15 per frame (-1: no face), only the source rows below the mask cross the link and
-    ``jg_mask_resize_packed`` (mask + cv2-style bilinear resize) builds the 270x480 crops on the device, on the upload stream.
+    ``jg_mask_resize_packed`` (mask + cv2-style bilinear resize) builds the 270x480 crops on the device, in front of the batch's compute.
     Bit-identical to ``load_rgb_masked_frames`` + the resident path.
 
     ``run(clips)``: ``clips`` iterates over (T,270,480,3) uint8 numpy arrays of one common T; yields
@@ -233,6 +233,7 @@ class GestureStreamer:
         self.copy = torch.cuda.Stream(dev)          # H2D
         self.down = torch.cuda.Stream(dev)          # D2H: on its own stream, or upload k+1 would queue behind `wait computed k`
         self.compute = torch.cuda.Stream(dev)
+        self._used = [0, 0]                         # packed bytes of the batch in each slot
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.computed = [torch.cuda.Event() for _ in range(2)]
         self.downloaded = [torch.cuda.Event() for _ in range(2)]
@@ -271,32 +272,34 @@ class GestureStreamer:
         return self.run_filled(lambda buf, k: self._pack(it, k & 1, rows_it))
 
     def _upload(self, slot, n):
-        """H2D of batch `slot` on the copy stream (+ the unpack kernel of the masked mode, also there)."""
+        """H2D of batch `slot` on the copy stream.  The kernel that rebuilds the dense batch from the packed rows (_unpack) is NOT
+        issued here: beside the persistent compute kernels of the previous batch it cost that batch 1.5-2.7 ms (its workgroups
+        take CUs the one-workgroup-per-CU kernels were launched for), in front of its own batch on the compute stream it costs its
+        stand-alone 1.0 ms (tools/stream_timeline.py: 15.3 -> 13.6 ms per streamed batch)."""
         with torch.cuda.stream(self.copy):
-            if self.source_hw is not None:
+            if self.masked:
                 pk = self.packer[slot]
                 F = n * self.T
                 self.d_packed[slot][:pk.used].copy_(pk.buf[:pk.used], non_blocking=True)
-                self.d_row0[slot][:F].copy_(pk.mask_y[:F], non_blocking=True)
+                self.d_row0[slot][:F].copy_((pk.mask_y if self.source_hw is not None else pk.row0)[:F], non_blocking=True)
                 self.d_offs[slot][:F].copy_(pk.offs[:F], non_blocking=True)
-                if pk.used == 0:                     # every frame masked completely: nothing crossed the link
-                    self.d_in[slot][:n].zero_()
-                else:
-                    self.eng.mask_resize_packed(self.d_packed[slot][:pk.used], self.d_offs[slot][:F], self.d_row0[slot][:F], self.source_hw[0],
-                                                self.source_hw[1], self.d_in[slot][:n])
-            elif self.masked:
-                pk = self.packer[slot]
-                F = n * self.T
-                self.d_packed[slot][:pk.used].copy_(pk.buf[:pk.used], non_blocking=True)
-                self.d_row0[slot][:F].copy_(pk.row0[:F], non_blocking=True)
-                self.d_offs[slot][:F].copy_(pk.offs[:F], non_blocking=True)
-                if pk.used == 0:
-                    self.d_in[slot][:n].zero_()
-                else:
-                    self.eng.unpack_masked(self.d_packed[slot][:pk.used], self.d_row0[slot][:F], self.d_offs[slot][:F], self.d_in[slot][:n])
+                self._used[slot] = pk.used
             else:
                 self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
             self.uploaded[slot].record(self.copy)
+
+    def _unpack(self, slot, n):
+        """Packed rows -> dense (n,T,270,480,3) batch on the CURRENT (compute) stream: jg_mask_resize_packed / jg_unpack_masked."""
+        if not self.masked:
+            return
+        F, used = n * self.T, self._used[slot]
+        if used == 0:                            # every frame masked completely: nothing crossed the link
+            self.d_in[slot][:n].zero_()
+        elif self.source_hw is not None:
+            self.eng.mask_resize_packed(self.d_packed[slot][:used], self.d_offs[slot][:F], self.d_row0[slot][:F], self.source_hw[0],
+                                        self.source_hw[1], self.d_in[slot][:n])
+        else:
+            self.eng.unpack_masked(self.d_packed[slot][:used], self.d_row0[slot][:F], self.d_offs[slot][:F], self.d_in[slot][:n])
 
     def run_filled(self, fill):
         """fill(buffer, batch_index) -> number of clips written (0 = end), for producers (decoders) that can write their crops
@@ -312,6 +315,7 @@ class GestureStreamer:
                 self._upload(slot, n)
                 with torch.cuda.stream(self.compute):
                     self.compute.wait_event(self.uploaded[slot])
+                    self._unpack(slot, n)
                     self.eng.extract_gesture(self.d_in[slot][:n], self.d_out[slot][:n])
                     self.computed[slot].record(self.compute)
                 with torch.cuda.stream(self.down):

@@ -145,7 +145,7 @@ def test_unpack_masked_rebuilds_the_dense_batch():
 def test_source_resolution_streamer_is_bit_identical(H, W):
     """GestureStreamer(source_hw=(H, W)) ships the decoder's frames (inference_embs.py:255-276 resizes 228x314 /
     294x294 crops up to 270x480 on the host) -- only the source rows below each frame's mask -- and jg_mask_resize_packed builds the
-    crops on the upload stream.  Embeddings must equal load_rgb_masked_frames' crops (jg_mask_resize of the full frames, itself
+    crops on the device.  Embeddings must equal load_rgb_masked_frames' crops (jg_mask_resize of the full frames, itself
     bit-exact against the oracle's cv2 restatement) through the resident path, bit for bit; the packed kernel alone equals the
     unpacked one, incl. no-face frames (-1), a fully masked frame and mask_y beyond the frame."""
     from jegal_amd._lib import Engine

@@ -1,5 +1,5 @@
-"""Where a streamed batch's time goes (GestureStreamer(source_hw=...), packers pre-filled): per batch, on one clock, the H2D copies,
-the mask + resize kernel and the compute call, from torch events -- is the steady state bound by the link, the compute, or a gap?
+"""Where a streamed batch's time goes (GestureStreamer(source_hw=...), packers pre-filled): per batch, on one clock, the H2D copies
+and the compute call (mask + resize kernel included), from torch events -- is the steady state bound by the link, the compute, or a gap?
 Usage: python tools/stream_timeline.py [batches]"""
 import os, sys, time
 import numpy as np, torch
@@ -74,5 +74,5 @@ if not MARKS:
     sys.exit(0)
 base = st.marks[0][0]
 for i, (e0, e1, c0, c1) in enumerate(st.marks):
-    print(f"batch {i}: upload+resize {base.elapsed_time(e0):7.2f} .. {base.elapsed_time(e1):7.2f} ms ({e0.elapsed_time(e1):5.2f}),"
+    print(f"batch {i}: upload {base.elapsed_time(e0):7.2f} .. {base.elapsed_time(e1):7.2f} ms ({e0.elapsed_time(e1):5.2f}),"
           f" compute {base.elapsed_time(c0):7.2f} .. {base.elapsed_time(c1):7.2f} ms ({c0.elapsed_time(c1):5.2f})")
