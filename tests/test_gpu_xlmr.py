@@ -41,7 +41,7 @@ def test_xlmr_matches_transformers_golden(xlmr, golden_dir):
     assert rel(out1, torch.from_numpy(g["last_hidden_state_nomask"])) < TOL
 
 
-@pytest.mark.parametrize("B,L", [(1, 3), (2, 33), (5, 70), (2, 200), (1, 512)])
+@pytest.mark.parametrize("B,L", [(1, 3), (2, 33), (5, 70), (2, 200), (1, 512), (103, 160)])      # (103, 160): two lanes of 8 160 / 8 320 rows -- 256x256 tiles, the last one partial along M
 def test_xlmr_lengths_vs_oracle(xlmr, B, L):
     """Short, odd and long sequences (MFMA attention up to 160 tokens, the VALU kernel beyond; 512 = the position table's limit),
     ragged padding, against the fp32 restatement."""
