@@ -1681,6 +1681,20 @@ int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int 
         a.res16 = o16; a.res8 = reinterpret_cast<signed char*>(x32); a.out16 = o16; a.out8 = reinterpret_cast<signed char*>(x32);
         a.ln_w = bias; a.ln_b = bias; a.ln_flavour = LN_STD;
     }
+    if (mode & 48) {     // implicit LayerNorm, timing only: 16 = consumer (ln_mode 1), 32 = producer (ln_mode 2); statistics / planes = the scratch buffers
+        float* stats;
+        RET(wsalloc(h, (size_t)pad128(M) * 2, &stats));
+        HIPCHK(h, hipMemsetAsync(stats, 0, (size_t)M * 2 * 4, h->stream));
+        a.res = nullptr; a.out32 = nullptr; a.scale = bias; a.ln_stats = stats;
+        if (mode & 16) { a.ln_mode = 1; a.out16 = o16; }
+        else {
+            f16* lo;
+            float* part;
+            RET(wsalloc(h, pad128(M) * N, &lo));
+            RET(wsalloc(h, (size_t)pad128(M) * (N / 64) * 2, &part));
+            a.ln_mode = 2; a.relu = 0; a.xres_hi = o16; a.xres_lo = lo; a.out16 = o16; a.out_lo = lo; a.stat_out = part;
+        }
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
