@@ -166,6 +166,7 @@ struct jg_handle {
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
     bool dual_stream = true;
     int dual_split = 3;            // the first lane gets dual_split/8 of the batch
+    int dual_split32 = 0;          // option "dual_split32" (experiments): the first lane gets this many 32nds of the batch instead (0: use dual_split)
     std::map<hipStream_t, Arena> ws_parked;      // arenas of the other streams this handle has been bound to (jg_set_stream)
     static constexpr int MAX_LANES = 4;
     hipStream_t lane_stream[MAX_LANES] = {};
@@ -1367,7 +1368,7 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int equal_lanes = 0) 
     const int nl = equal_lanes ? equal_lanes : 2;
     int start[jg_handle::MAX_LANES + 1];
     start[0] = 0;
-    for (int l = 1; l <= nl; ++l) start[l] = equal_lanes ? (int)((long)B * l / nl) : (l == 1 ? (B * h->dual_split + 4) / 8 : B);
+    for (int l = 1; l <= nl; ++l) start[l] = equal_lanes ? (int)((long)B * l / nl) : (l == 1 ? (h->dual_split32 ? (B * h->dual_split32 + 16) / 32 : (B * h->dual_split + 4) / 8) : B);
     int smallest = B;
     for (int l = 0; l < nl; ++l) smallest = std::min(smallest, start[l + 1] - start[l]);
     if (!h->dual_stream || h->calib || nl < 2 || B < 8 || (long)smallest * T < 256) return run_part(0, B);
@@ -1504,6 +1505,11 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
         return JG_OK;
     }
     if (!std::strcmp(name, "xlmr_fold")) { h->xl_fold_opt = value != 0; return JG_OK; }       // takes effect at the next jg_finalize_weights(h, 4)
+    if (!std::strcmp(name, "dual_split32")) {
+        if (value < 0 || value > 31) JG_FAIL(h, JG_ERR_ARG, "dual_split32 must be 0..31 (32nds of the batch on the first lane; 0 = use dual_split)");
+        h->dual_split32 = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "dual_split")) {
         if (value < 1 || value > 7) JG_FAIL(h, JG_ERR_ARG, "dual_split must be 1..7 (eighths of the batch on the first lane)");
         h->dual_split = value;
