@@ -27,52 +27,120 @@ def sinusoid_pe(max_len, d_model):
     return pe.unsqueeze(0).numpy()
 
 
+FAMILIES = ("gauss", "heavy", "sharp")
+
+
+def _relu_moments(mu, sigma):
+    """E[relu(z)], E[relu(z)^2] for z ~ N(mu, sigma^2), per element."""
+    from math import erf, exp, pi, sqrt
+    mu = np.asarray(mu, np.float64)
+    sigma = np.maximum(np.asarray(sigma, np.float64), 1e-12)
+    r = mu / sigma
+    Phi = 0.5 * (1.0 + np.vectorize(erf)(r / sqrt(2.0)))
+    phi = np.exp(-0.5 * r * r) / sqrt(2.0 * pi)
+    return mu * Phi + sigma * phi, (mu * mu + sigma * sigma) * Phi + mu * sigma * phi
+
+
 class _Gen:
-    def __init__(self, seed):
+    """Seeded weight generator.  ``family`` (every parity number of rounds 1-4 came from ONE draw of
+    He-initialised Gaussian weights, while the reference runs trained checkpoints, inference_embs.py:92-119):
+
+    "gauss"  the original draw (bit-identical to rounds 1-4 for the default seeds; the goldens depend on it)
+    "heavy"  Student-t (nu = 3, rescaled to the Gaussian family's variance) weights -- outliers of tens of sigma; BatchNorm
+             running_var log-uniform in [1e-2, 1e1] and BatchNorm / LayerNorm gamma log-uniform in [0.1, 4].  The conv weights in
+             front of a BatchNorm are rescaled per output channel so that the pre-BN variance is about running_var (a trained
+             net's statistics are self-consistent: without that the activations leave fp16's range after two layers) and
+             running_mean sits near the pre-BN mean.
+    "sharp"  the Gaussian draw with the q and k projections of every attention x 4 (logits x 16: near one-hot softmax)
+    """
+
+    def __init__(self, seed, family="gauss"):
+        if family not in FAMILIES:
+            raise ValueError(f"unknown weight family {family!r} (one of {FAMILIES})")
         self.rng = np.random.default_rng(seed)
         self.sd = {}
+        self.family = family
+        self.in_m1, self.in_m2 = 0.5, 1.0 / 3.0      # first / second moment of the next conv's input (heavy family bookkeeping)
+
+    def _randn(self, shape):
+        if self.family == "heavy":
+            return self.rng.standard_t(3.0, shape) / math.sqrt(3.0)
+        return self.rng.standard_normal(shape)
+
+    def _gamma(self, c, lo, hi):
+        if self.family == "heavy":
+            return np.exp(self.rng.uniform(math.log(0.1), math.log(4.0), c)).astype(np.float32)
+        return self.rng.uniform(lo, hi, c).astype(np.float32)
 
     def linear(self, name, out_f, in_f, relu_after=False, wname="weight", bname="bias"):
         std = math.sqrt((2.0 if relu_after else 1.0) / in_f)
-        self.sd[f"{name}.{wname}"] = (self.rng.standard_normal((out_f, in_f)) * std).astype(np.float32)
+        self.sd[f"{name}.{wname}"] = (self._randn((out_f, in_f)) * std).astype(np.float32)
         self.sd[f"{name}.{bname}"] = (self.rng.standard_normal(out_f) * 0.05).astype(np.float32)
 
     def conv(self, name, out_c, in_c, ks):
         fan_in = in_c * int(np.prod(ks))
         std = math.sqrt(2.0 / fan_in)
-        self.sd[f"{name}.weight"] = (self.rng.standard_normal((out_c, in_c) + tuple(ks)) * std).astype(np.float32)
+        self.sd[f"{name}.weight"] = (self._randn((out_c, in_c) + tuple(ks)) * std).astype(np.float32)
         self.sd[f"{name}.bias"] = (self.rng.standard_normal(out_c) * 0.05).astype(np.float32)
+        self._last_conv = name
 
-    def bn(self, name, c):
-        self.sd[f"{name}.weight"] = self.rng.uniform(0.6, 1.4, c).astype(np.float32)
-        self.sd[f"{name}.bias"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
-        self.sd[f"{name}.running_mean"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
-        self.sd[f"{name}.running_var"] = self.rng.uniform(0.5, 1.5, c).astype(np.float32)
+    def bn(self, name, c, pooled=False):
+        if self.family != "heavy":
+            self.sd[f"{name}.weight"] = self.rng.uniform(0.6, 1.4, c).astype(np.float32)
+            self.sd[f"{name}.bias"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+            self.sd[f"{name}.running_mean"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+            self.sd[f"{name}.running_var"] = self.rng.uniform(0.5, 1.5, c).astype(np.float32)
+            self.sd[f"{name}.num_batches_tracked"] = np.array(1000, dtype=np.int64)
+            return
+        gamma = self._gamma(c, 0.6, 1.4)
+        beta = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
+        rv = np.exp(self.rng.uniform(math.log(1e-2), math.log(1e1), c)).astype(np.float32)
+        # rescale the conv in front: He weights give a pre-BN variance of 2 * E[x^2]; make it running_var per output channel
+        w = self.sd[f"{self._last_conv}.weight"]
+        w *= np.sqrt(rv / (2.0 * self.in_m2)).astype(np.float32).reshape((c,) + (1,) * (w.ndim - 1))
+        pre_mean = self.sd[f"{self._last_conv}.bias"] + self.in_m1 * w.reshape(c, -1).sum(1)
+        off = (self.rng.standard_normal(c) * 0.3).astype(np.float32)                 # BN input mean - running_mean, in sigmas
+        self.sd[f"{name}.weight"] = gamma
+        self.sd[f"{name}.bias"] = beta
+        self.sd[f"{name}.running_mean"] = (pre_mean - off * np.sqrt(rv)).astype(np.float32)
+        self.sd[f"{name}.running_var"] = rv
         self.sd[f"{name}.num_batches_tracked"] = np.array(1000, dtype=np.int64)
+        m1, m2 = _relu_moments(beta + gamma * off, gamma)
+        k = 1.6 if pooled else 1.0                   # a 3x3 max-pool behind the ReLU lifts the moments (rough: keeps the next layer in range)
+        self.in_m1, self.in_m2 = float(m1.mean()) * k, float(m2.mean()) * k * k
 
     def ln(self, name, c, wname="weight", bname="bias"):
-        self.sd[f"{name}.{wname}"] = self.rng.uniform(0.7, 1.3, c).astype(np.float32)
+        self.sd[f"{name}.{wname}"] = self._gamma(c, 0.7, 1.3)
         self.sd[f"{name}.{bname}"] = (self.rng.standard_normal(c) * 0.1).astype(np.float32)
 
+    def sharpen(self, wkey, bkey, rows=None):
+        """'sharp' family: q / k projection (rows of a packed in_proj, or a whole Linear) x 4."""
+        if self.family != "sharp":
+            return
+        sl = slice(None) if rows is None else slice(0, rows)
+        self.sd[wkey][sl] *= np.float32(4.0)
+        self.sd[bkey][sl] *= np.float32(4.0)
 
-def gestsync_state_dict(seed=GESTSYNC_SEED, include_unused=True):
+
+def gestsync_state_dict(seed=GESTSYNC_SEED, include_unused=True, family="gauss"):
     """All keys of ``GestSync().state_dict()`` (gestsync.py:9-32).
 
     ``include_unused`` adds the audio/LSTM tensors the checkpoint carries but
-    ``forward_vid`` never touches (checkpoint row).
+    ``forward_vid`` never touches (checkpoint row).  ``family``: see _Gen.
     """
-    g = _Gen(seed)
+    g = _Gen(seed, family)
     vid = [("conv1", 64, 3, (5, 7, 7)), ("conv2", 128, 64, (1, 5, 5)), ("conv3", 256, 128, (1, 3, 3)),
            ("conv4", 256, 256, (1, 3, 3)), ("conv5", 256, 256, (1, 3, 3)), ("fc6", 512, 256, (1, 4, 4))]
     for i, (nm, oc, ic, ks) in enumerate(vid, 1):
         g.conv(f"net_vid.{nm}", oc, ic, ks)
-        g.bn(f"net_vid.bn{i}", oc)
+        g.bn(f"net_vid.bn{i}", oc, pooled=nm in ("conv1", "conv5"))
     g.linear("ff_vid.0", 512, 512, relu_after=True)
     g.linear("ff_vid.2", 1024, 512)
     g.sd["pos_encoder.pe"] = sinusoid_pe(50, 512)
     for l in range(6):
         p = f"transformer_encoder.layers.{l}"
         g.linear(f"{p}.self_attn", 1536, 512, wname="in_proj_weight", bname="in_proj_bias")
+        g.sharpen(f"{p}.self_attn.in_proj_weight", f"{p}.self_attn.in_proj_bias", rows=1024)
         g.linear(f"{p}.self_attn.out_proj", 512, 512)
         g.linear(f"{p}.linear1", 2048, 512, relu_after=True)
         g.linear(f"{p}.linear2", 512, 2048)
@@ -103,6 +171,8 @@ def _annotated_encoder(g, prefix, n_layers, d, d_ff):
         p = f"{prefix}.layers.{l}"
         for i in range(4):
             g.linear(f"{p}.self_attn.linears.{i}", d, d)
+            if i < 2:
+                g.sharpen(f"{p}.self_attn.linears.{i}.weight", f"{p}.self_attn.linears.{i}.bias")
         g.linear(f"{p}.feed_forward.w_1", d_ff, d, relu_after=True)
         g.linear(f"{p}.feed_forward.w_2", d, d_ff)
         g.ln(f"{p}.sublayer.0.norm", d, "a_2", "b_2")
@@ -110,9 +180,9 @@ def _annotated_encoder(g, prefix, n_layers, d, d_ff):
     g.ln(f"{prefix}.norm", d, "a_2", "b_2")
 
 
-def jegal_state_dict(seed=JEGAL_SEED):
-    """All keys of ``JEGAL().state_dict()`` (jegal.py:18-76)."""
-    g = _Gen(seed)
+def jegal_state_dict(seed=JEGAL_SEED, family="gauss"):
+    """All keys of ``JEGAL().state_dict()`` (jegal.py:18-76).  ``family``: see _Gen."""
+    g = _Gen(seed, family)
     g.linear("proj_ip_rgb.0", 512, 1024)
     g.ln("proj_ip_rgb.1", 512)
     g.linear("proj_ip_rgb.3", 512, 512)
@@ -123,6 +193,7 @@ def jegal_state_dict(seed=JEGAL_SEED):
     g.linear("proj_op_text", 256, 768)
     cnn = [(0, 32, 1, (5, 5)), (3, 64, 32, (3, 3)), (6, 128, 64, (3, 3)), (9, 256, 128, (3, 3)),
            (12, 256, 256, (3, 3)), (15, 256, 256, (1, 1))]
+    g.in_m1, g.in_m2 = 8.0, 8.0 * 8.0 + 2.5 * 2.5          # log-mel input ~ N(8, 2.5) (heavy family bookkeeping)
     for idx, oc, ic, ks in cnn:
         g.conv(f"cnn.{idx}", oc, ic, ks)
         if idx != 15:
@@ -137,11 +208,11 @@ def jegal_state_dict(seed=JEGAL_SEED):
 XLMR_SEED = 4242
 
 
-def xlmr_state_dict(seed=XLMR_SEED, vocab=1000, layers=4, max_pos=514):
+def xlmr_state_dict(seed=XLMR_SEED, vocab=1000, layers=4, max_pos=514, family="gauss"):
     """Keys and shapes of ``transformers.XLMRobertaModel(...).state_dict()`` for the xlm-roberta-base architecture (hidden 768,
     12 heads, intermediate 3072, type vocabulary 1) with a reduced vocabulary / depth: seeded random stand-ins for the released
     checkpoint, which is not available offline (jegal.py:13-14).  Weight scales keep the activations O(1) through the layers."""
-    g = _Gen(seed)
+    g = _Gen(seed, family)
     D, DFF = 768, 3072
     g.sd["embeddings.word_embeddings.weight"] = (g.rng.standard_normal((vocab, D)) * 0.5).astype(np.float32)
     g.sd["embeddings.position_embeddings.weight"] = (g.rng.standard_normal((max_pos, D)) * 0.3).astype(np.float32)
@@ -151,6 +222,8 @@ def xlmr_state_dict(seed=XLMR_SEED, vocab=1000, layers=4, max_pos=514):
         p = f"encoder.layer.{l}"
         for nm in ("query", "key", "value"):
             g.linear(f"{p}.attention.self.{nm}", D, D)
+            if nm != "value":
+                g.sharpen(f"{p}.attention.self.{nm}.weight", f"{p}.attention.self.{nm}.bias")
         g.linear(f"{p}.attention.output.dense", D, D)
         g.ln(f"{p}.attention.output.LayerNorm", D)
         g.linear(f"{p}.intermediate.dense", DFF, D, relu_after=True)

@@ -139,7 +139,31 @@ def golden_xlmr(layers_arg=None, fname="xlmr.npz", seed=9011, B=3, L=24):
     print("xlmr golden", fname, ":", out.shape, layers, "layers, transformers", transformers.__version__)
 
 
+def golden_logmel():
+    """(viii) log-mel front end from the reference ITSELF: utils/audio_utils.py imports librosa at module
+    level but wav2filterbanks takes `mel_basis` as a parameter (:28,:54-62), so with an empty `librosa` module in sys.modules the
+    reference's own load_wav + wav2filterbanks run here on its own samples/sample1.wav.  Stored: the (216,80) features, the
+    sample count and a checksum of the raw samples load_wav returned.  mel_basis = jegal_amd.audio.mel_filterbank() (the
+    librosa.filters.mel restatement stays unpinned: librosa is absent)."""
+    import hashlib
+    from jegal_amd import audio
+    sys.modules.setdefault("librosa", types.ModuleType("librosa"))
+    sys.path.insert(0, REF)
+    from utils import audio_utils as ref_audio
+    wav = ref_audio.load_wav(os.path.join(REF, "samples", "sample1.wav"))
+    mel_basis = torch.from_numpy(audio.mel_filterbank())
+    with torch.no_grad():
+        feats = ref_audio.wav2filterbanks(torch.FloatTensor(wav).unsqueeze(0), mel_basis=mel_basis)[0]
+    np.savez_compressed(os.path.join(OUT, "logmel_sample1.npz"), features=feats[0].numpy(), n_samples=np.int64(wav.shape[0]),
+                        wav_dtype=str(wav.dtype), wav_sha256=hashlib.sha256(np.ascontiguousarray(wav).tobytes()).hexdigest())
+    print("logmel_sample1.npz:", tuple(feats.shape), wav.dtype, wav.shape)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "logmel":        # regenerate only tests/golden/logmel_sample1.npz
+        os.makedirs(OUT, exist_ok=True)
+        golden_logmel()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "asd":           # regenerate only tests/golden/asd.npz
         golden_asd(_import_eval("evaluate_asd"))
         return
@@ -246,6 +270,7 @@ def main():
         res[s] = {"text": text, "word_boundaries": wbs, "file": open(os.path.join(REF, "samples", s + ".txt"), encoding="utf-8").read()}
     with open(os.path.join(OUT, "load_text.json"), "w") as f:
         json.dump(res, f, indent=1)
+    golden_logmel()
     print("golden vectors written to", OUT)
 
 

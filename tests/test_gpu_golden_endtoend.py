@@ -318,6 +318,9 @@ def test_logmel_frontend(engine):
     f1, _, _, _ = audio.wav2filterbanks(torch.from_numpy(wav1)[None].cuda(), engine=engine)
     assert f1.shape == (1, 216, 80)
     assert rel(f1, O.wav2filterbanks(wav1[None], mb.cpu())) < 1e-5
+    # ... and against the reference's own wav2filterbanks output for that file (tests/golden/logmel_sample1.npz, make_golden.py logmel)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "logmel_sample1.npz"))["features"]
+    assert rel(f1[0], gold) < 1e-5 and float(np.abs(f1[0].cpu().numpy() - gold).max()) < 2e-3
 
 
 def test_precision_modes(oracle_sd):

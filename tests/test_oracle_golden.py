@@ -176,3 +176,19 @@ def test_xlmr_oracle_matches_transformers_12_layers(golden_dir):
         out = O.xlmr_forward(sd, g["input_ids"], g["attention_mask"]).numpy()
     m = g["attention_mask"].astype(bool)
     assert np.abs(out[m] - g["last_hidden_state"][m]).max() < 5e-5
+
+
+def test_logmel_oracle_and_load_wav_match_the_reference(golden_dir):
+    """tests/golden/logmel_sample1.npz holds what the reference's OWN utils/audio_utils.py (load_wav :20-25,
+    wav2filterbanks :28-66, imported with an empty librosa module; mel_basis passed in) returns for its samples/sample1.wav.  The
+    oracle's torch.stft restatement and the package's load_wav are held to it; the mel basis itself (librosa.filters.mel) stays
+    unpinned -- both sides take jegal_amd.audio.mel_filterbank()."""
+    import hashlib
+    from jegal_amd import audio
+    g = np.load(os.path.join(golden_dir, "logmel_sample1.npz"))
+    wav = audio.load_wav(os.path.join(golden_dir, "sample1.wav"))
+    assert str(wav.dtype) == str(g["wav_dtype"]) and wav.shape == (int(g["n_samples"]),)
+    assert hashlib.sha256(np.ascontiguousarray(wav).tobytes()).hexdigest() == str(g["wav_sha256"])
+    feats = O.wav2filterbanks(wav.astype("float32")[None], torch.from_numpy(audio.mel_filterbank()))[0].numpy()
+    assert feats.shape == g["features"].shape == (216, 80)
+    assert np.abs(feats - g["features"]).max() <= 1e-6
