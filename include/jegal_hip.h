@@ -36,13 +36,18 @@ enum {
     JG_PREC_FP16_BC = 3,  /* default: single fp16 weights on the gesture path, the systematic part of the weight
                              rounding error (w - fp16(w)).E[x] folded into the bias by a calibration pass run inside
                              jg_finalize_weights; content-path Linears keep the hi+lo split */
-    JG_PREC_BF16 = 4      /* REPORTED mode (north_star names bf16): every weight and every 16-bit activation is bf16 and every
+    JG_PREC_BF16 = 4,     /* REPORTED mode (north_star names bf16): every weight and every 16-bit activation is bf16 and every
                              MFMA is a bf16 MFMA (v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, the second build of the kernels,
                              namespace bf).  Same MFMA rate as fp16, 8 instead of 11 significant bits: the embeddings come out
                              at ~5e-3 of the reference, outside the 1e-3 contract -- which is why fp16 is the default
-                             (tests/test_gpu_parity_r3.py::test_precision_modes_report prints the measured errors side by side).
-                             conv1 runs as an implicit GEMM over stacked frames and the LayerNorms as separate kernels in
+                             (tests/test_gpu_precision_uploads.py::test_precision_modes_report prints the measured errors side by
+                             side).  conv1 runs as an implicit GEMM over stacked frames and the LayerNorms as separate kernels in
                              this mode (the fused u8 conv1 kernel and the fp16 + fp8 token stream are fp16 constructs). */
+    JG_PREC_FP16_RC = 5   /* run-time corrected: as JG_PREC_FP16_BC, but the term (w - fp16(w)).E[x] of every GestSync transformer
+                             Linear is rebuilt per GEMM call and per clip from a fixed sample of THAT clip's own input rows (two small
+                             launches in front of the GEMM, a per-clip bias in its epilogue) -- no calibration pass, nothing depends on
+                             calibration data or on the other clips of a batch.  The JEGAL branch and the content path run hi+lo.
+                             What the CLI drivers select for a checkpoint they have never seen (jegal_amd/drivers.py). */
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -71,7 +76,7 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16 + fp8 token stream)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
  *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
- *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_parity.py flips every one of them)
+ *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_options_scale_multirank.py flips every one of them)
  *   "gemm_tile"       0: plain GEMMs pick their tile by a measured cost estimate; 1 / 2 / 3: force 128x128 / 256x128 / 256x256 (bit-identical)
  *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and run the two parts concurrently on two internal
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills

@@ -53,6 +53,9 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     // the weight-rounding error, (w - fp16(w)) . E[x], is folded into `bias` after a calibration pass that runs
     // with hi+lo weights (wl_calib) and records the per-channel mean of this layer's input (mu).
     bool bc = false;
+    // run-time corrected mode (JG_PREC_FP16_RC; GestSync transformer Linears): single fp16 `wh` + a per-clip bias built from the clip's own
+    // rows and the lo part (`wl_calib`), see gemm(); wherever that epilogue is not available the GEMM runs hi+lo instead
+    bool rc = false;
     bool bc_pending = false;    // LK_XLMR: no calibration yet -- the run-time GEMM keeps using hi+lo (wl == wl_calib); jg_calibrate_xlmr clears it
     f16* wl_calib = nullptr;
     float* mu = nullptr;        // device [K]: column sums of the A operand seen during calibration
@@ -272,11 +275,16 @@ enum { LK_CONV = 0, LK_GESTURE = 1, LK_CONTENT = 2, LK_XLMR = 3 };      // LK_XL
 
 int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L, bool ln_consumer = false) {
     const int mode = h->precision;
-    const bool bc = mode == JG_PREC_FP16_BC && (kind == LK_GESTURE || kind == LK_XLMR);
+    // JG_PREC_FP16_RC: GestSync's Linears (model 1) are run-time corrected; the JEGAL gesture branch (M = B*T rows: launch-bound, a
+    // 256-row tile meets several clips) and the content path keep hi+lo; XLM-RoBERTa as in JG_PREC_FP16_BC (hi+lo until calibrated)
+    const bool rcm = mode == JG_PREC_FP16_RC;
+    const bool rc = rcm && kind == LK_GESTURE && h->cur_model == 1;
+    const bool bc = (mode == JG_PREC_FP16_BC && (kind == LK_GESTURE || kind == LK_XLMR)) || (rcm && kind == LK_XLMR);
     const bool split = kind == LK_CONV ? mode == JG_PREC_FP16_W2_ALL
-                                       : (mode == JG_PREC_FP16_W2 || mode == JG_PREC_FP16_W2_ALL || (mode == JG_PREC_FP16_BC && kind == LK_CONTENT));
+                                       : (mode == JG_PREC_FP16_W2 || mode == JG_PREC_FP16_W2_ALL || (mode == JG_PREC_FP16_BC && kind == LK_CONTENT) ||
+                                          (rcm && !rc && kind != LK_XLMR));
     std::vector<f16> hi((size_t)N * K), lo;
-    if (split || bc) lo.resize((size_t)N * K);
+    if (split || bc || rc) lo.resize((size_t)N * K);
     if (h->bf16) {                       // JG_PREC_BF16: single bf16 weights (the 16-bit container is re-typed by the bf16 build)
         for (size_t i = 0; i < hi.size(); ++i) {
             const uint16_t b = bf16_bits(w[i]);
@@ -286,7 +294,7 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
         for (size_t i = 0; i < hi.size(); ++i) {
             const f16 a = (f16)w[i];
             hi[i] = a;
-            if (split || bc) lo[i] = (f16)(w[i] - (float)a);
+            if (split || bc || rc) lo[i] = (f16)(w[i] - (float)a);
         }
     }
     L->N = N; L->K = K;
@@ -321,7 +329,9 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     if (split) RET(upload(h, lo, &L->wl));
     RET(upload(h, bias, &L->bias));
     L->bc = bc;
+    L->rc = rc;
     L->bc_pending = false;
+    if (rc) RET(upload(h, lo, &L->wl_calib));
     if (bc) {
         RET(upload(h, lo, &L->wl_calib));
         RET(walloc<float>(h, (size_t)K, &L->mu));
@@ -551,6 +561,8 @@ struct Epi {
     f16* x_lo = nullptr;
     const float* ln_gamma = nullptr;
     float* stat_out = nullptr;
+    // JG_PREC_FP16_RC: the M rows are rc_clips clips of rc_rpc rows each (0: no clip structure -> a run-time corrected layer runs hi+lo)
+    int rc_rpc = 0, rc_clips = 0;
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -559,6 +571,24 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     a.A = A; a.lda = lda;
     if (g) a.g = *g;
     a.Wh = L.wh; a.Wl = (h->calib && L.bc) ? L.wl_calib : L.wl; a.ldw = L.K;
+    const bool conv = g != nullptr;
+    if (L.rc) {
+        // run-time correction: bias_clip = bias + lo . (mean of a sample of the clip's own rows), two small launches in front of the GEMM;
+        // only the LDS-DMA kernel's fp16-row and LayerNorm-fused epilogues take it (launch_gemm), everything else runs hi+lo
+        const bool ln_fused = e.ln && e.res16;
+        const bool rows16 = e.out16 && !e.out32 && !e.res && !e.ln;
+        const bool can = !conv && !e.ln_mode && !e.no_bias && h->opts.gemm_glds && e.rc_rpc >= 256 && e.rc_clips > 0 && (long)e.rc_rpc * e.rc_clips == M &&
+                         M >= 1024 && (L.K == 512 || L.K == 2048) && L.N % 128 == 0 && (ln_fused || rows16) && (!e.a_tiled || L.K == 512);
+        if (can) {
+            float *scr, *bc;
+            RET(wsalloc(h, rc_scratch_elems(e.rc_clips, L.K), &scr));
+            RET(wsalloc(h, (size_t)e.rc_clips * L.N, &bc));
+            RET(timed(h, JG_ST_MISC, [&] { return launch_rc_bias(A, lda, e.a_tiled, e.rc_clips, e.rc_rpc, L.wl_calib, L.bias, L.N, L.K, scr, bc, h->stream); }));
+            a.bias_clip = bc; a.rpc = e.rc_rpc; a.nclips = e.rc_clips;
+        } else {
+            a.Wl = L.wl_calib;
+        }
+    }
     a.M = M; a.N = L.N; a.K = L.K;
     a.scale = e.scale; a.bias = e.no_bias ? nullptr : L.bias;
     a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
@@ -573,7 +603,6 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
         a.ln_mode = 2; a.ln_stats = e.ln_stats; a.scale = e.ln_gamma;
         a.xres_hi = e.x_hi; a.xres_lo = e.x_lo; a.out16 = e.x_hi; a.out_lo = e.x_lo; a.stat_out = e.stat_out;
     }
-    const bool conv = g != nullptr;
     if (h->calib && L.bc && !conv) {
         // column sums ACCUMULATE over every call of a calibration pass (chunks of a large calibration batch, the six
         // layers' shared shapes are separate Lin objects): calibrate_impl zeroes mu / mu_rows once at its start
@@ -764,8 +793,11 @@ struct Qkv0 {
     int nclip, P, Twin, shift;
 };
 
-int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled, const Qkv0* q0 = nullptr) {
+// rc_clips > 0: the rows are rc_clips clips of M / rc_clips rows each (the clip path; JG_PREC_FP16_RC's per-clip corrections)
+int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled, const Qkv0* q0 = nullptr, int rc_clips = 0) {
     const int M = nseq * S;
+    const int rc_rpc = rc_clips > 0 && tiled ? M / rc_clips : 0;
+    if (!rc_rpc) rc_clips = 0;
     f16 *qkv, *att, *hid;
     RET(wsalloc(h, (size_t)M * 1536, &qkv));
     RET(wsalloc(h, (size_t)M * 512, &att));
@@ -790,7 +822,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             RET(timed(h, JG_ST_ATTN, [&] { return launch_attention_gather(qpos, ag, nseq, S, 8, att, h->stream); }));
         } else {
             Epi e;
-            e.out16 = qkv; e.a_tiled = tiled;
+            e.out16 = qkv; e.a_tiled = tiled; e.rc_rpc = rc_rpc; e.rc_clips = rc_clips;
             RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
             RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
         }
@@ -800,6 +832,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             Epi r;
             if (tiled) {
                 r.res16 = x16; r.res8 = d8; r.out16 = x16; r.out8 = d8; r.ln = &ln; r.ln_flavour = LN_STD;
+                r.rc_rpc = rc_rpc; r.rc_clips = rc_clips;
                 return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
             }
             r.res = x32; r.ldr = 512; r.out32 = x32;
@@ -808,7 +841,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
         };
         RET(proj_ln(att, 512, L.out, L.n1));
         Epi f;
-        f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
+        f.relu = 1; f.out16 = hid; f.a_tiled = tiled; f.rc_rpc = rc_rpc; f.rc_clips = rc_clips;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.ff1, f));
         RET(proj_ln(hid, 2048, L.ff2, L.n2));
     }
@@ -845,10 +878,11 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(wsalloc(h, pad128(M) * 512, &x16));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
         const Qkv0 q0 = {conv16, nb, P, T, 12 - PAD};
-        RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr));
+        RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr, nb));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
         Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
+        if (tiled) { f.rc_rpc = T * S; f.rc_clips = nb; }
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_group_mean, hid, nseq, S, 512, mean16, h->stream); }));
         Epi o; o.out32 = out_feats + (size_t)b0 * T * 1024;
@@ -1474,7 +1508,7 @@ int jg_set_stream(jg_handle* h, void* s) {
 
 int jg_set_precision(jg_handle* h, int mode) {
     if (!h) return JG_ERR_ARG;
-    if (mode < JG_PREC_FP16 || mode > JG_PREC_BF16) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
+    if (mode < JG_PREC_FP16 || mode > JG_PREC_FP16_RC) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
     if ((h->gs_ready || h->jg_ready || h->xl_ready) && mode != h->precision) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
     h->precision = mode;
     h->bf16 = mode == JG_PREC_BF16;

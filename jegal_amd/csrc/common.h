@@ -136,6 +136,11 @@ struct GemmArgs {
     const f16* xres_lo;
     f16* out_lo;               // mode 2: lo plane of the output
     float* stat_out;           // mode 2: [M][N / 64][2]
+    // Per-clip bias (precision mode JG_PREC_FP16_RC, launch_rc_bias): row m takes bias_clip[min(m / rpc, nclips - 1)][n] instead of
+    // bias[n].  LDS-DMA kernel only, through the fp16 row-transposing epilogue (out16 alone, no residual) or the LayerNorm-fused one;
+    // launch_gemm rejects anything else -- there is no path that would quietly drop the correction.
+    const float* bias_clip;    // [nclips][N] (the layer's bias already inside) or nullptr
+    int rpc, nclips;
 };
 
 // ---- tiled token stream (N = 512 columns, row tiles of 128) -----------------------------------------------------
@@ -273,6 +278,11 @@ hipError_t launch_logmel(const float* wav, int B, int n_samples, const float* me
 // stats != nullptr ([M][2] mean, rstd): sums of the NORMALISED rows (A[m][k] - mean[m]) * rstd[m] (calibration of an implicit-LayerNorm consumer)
 hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, float* out, hipStream_t s, const float* stats = nullptr);
 size_t col_sum_scratch_elems(int K);
+// JG_PREC_FP16_RC: out[c][n] = bias[n] + sum_k lo[n][k] * (mean over a fixed sample of clip c's rows of A[.][k]); clip c = rows c*rpc .. +rpc-1 of
+// A (row-major [.][lda], or the tiled fp16 token plane when `tiled`: K == 512); scratch: rc_scratch_elems(nclips, K) floats
+hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const f16* lo, const float* bias, int N, int K, float* scratch,
+                          float* out, hipStream_t s);
+size_t rc_scratch_elems(int nclips, int K);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,
                            int32_t* rank, int32_t* ties, hipStream_t s);

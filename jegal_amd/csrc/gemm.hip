@@ -589,7 +589,6 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         const bool rows16 = ROWS_OK && interior && a.out16 && !a.out32 && !ares && (a.ldc & 7) == 0;
         // implicit LayerNorm (XE instances; launch_gemm checks the shapes): 1 = consumer, through the rows16 path with per-row
         // (rstd, mean) factors; 2 = producer, the two-plane path below
-        constexpr int xmode = XE;
         const int orow_m = cm0 + wm * (16 * MI) + (lane >> 3);
         // ConvGeom::rowmap: the full output rows of this wave's 16*MI tile rows (both store paths below stay inside them) go
         // through a per-wave table in LDS -- 1-2 loads per lane, in front of the next tile's setup and OLDER than its first DMA,
@@ -637,11 +636,23 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
             // bias / gamma / beta come from LDS (3 x 512 floats, re-staged per tile: the k loop owns the LDS).
             constexpr int JD = 2;                                         // row block in front of which the next tile's DMA goes
             float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
-            float* lnp = red + 2 * 8 * BM;                                // [3][BN]: bias, gamma, beta
+            float* lnp = red + 2 * 8 * BM;                                // [4][BN]: bias, gamma, beta, bias of the tile's second clip
+            // per-clip bias (GemmArgs::bias_clip): a 128-row tile meets at most two clips when rpc >= 128 (launch_gemm checks); rows from
+            // csplit on take the second clip's vector
+            const float* b0 = a.bias;
+            const float* b1 = a.bias;
+            int csplit = 0x7fffffff;
+            if (a.bias_clip) {
+                const int c0 = cm0 / a.rpc;
+                b0 = a.bias_clip + (long)(c0 < a.nclips ? c0 : a.nclips - 1) * BN;
+                b1 = a.bias_clip + (long)(c0 + 1 < a.nclips ? c0 + 1 : a.nclips - 1) * BN;
+                csplit = (c0 + 1) * a.rpc;
+            }
             for (int c = t; c < BN; c += 512) {
-                lnp[c] = a.bias ? a.bias[c] : 0.f;
+                lnp[c] = b0 ? b0[c] : 0.f;
                 lnp[BN + c] = a.ln_w[c];
                 lnp[2 * BN + c] = a.ln_b[c];
+                lnp[3 * BN + c] = b1 ? b1[c] : 0.f;
             }
             __syncthreads();
             const int ncol = wn * 64 + fq * 4;                            // + i*16: this lane's 4 columns of block i
@@ -649,9 +660,10 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 float sj = 0.f;
+                const float* bsel = lnp + (cm0 + j * 16 + frow >= csplit ? 3 * BN : 0) + ncol;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(lnp + ncol + i * 16);
+                    const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(bsel + i * 16);
                     acc[i][j] = v;
                     sj += (v.x + v.y) + (v.z + v.w);
                 }
@@ -838,9 +850,20 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[i] = *reinterpret_cast<const f32x4*>(a.scale + nb + i * 16);
             }
-            if (a.bias) {
+            // per-clip bias (GemmArgs::bias_clip; plain instances): a tile inside one clip just takes that clip's vector; a tile that
+            // meets a clip boundary (one in twelve at 3150 rows per clip) picks the vector per 16-row block and lane
+            const float* bias_t = a.bias;
+            bool straddle = false;
+            if constexpr (!CONV && XE == 0) {
+                if (a.bias_clip) {
+                    const int c0 = cm0 / a.rpc;
+                    straddle = (cm0 + BM - 1) / a.rpc != c0;
+                    bias_t = a.bias_clip + (long)(c0 < a.nclips ? c0 : a.nclips - 1) * a.N;
+                }
+            }
+            if (bias_t) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(a.bias + nb + i * 16);
+                for (int i = 0; i < 4; ++i) bi[i] = *reinterpret_cast<const f32x4*>(bias_t + nb + i * 16);
             }
             f16* ocol = a.out16 + cn0 + wn * 64 + (lane & 7) * 8;
             // ln_mode 1: out = rstd[m] * (acc - mean[m] * c1[n]) + bias[n], c1 (column sums of the folded weights) in `sc`
@@ -863,14 +886,21 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
                     }
                 }
             }
-            auto store_rows = [&](auto masked_tag) __attribute__((always_inline)) {
+            auto store_rows = [&](auto masked_tag, auto straddle_tag) __attribute__((always_inline)) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
+                constexpr bool STRADDLE = decltype(straddle_tag)::value;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
+                    const float* bj = nullptr;
+                    if constexpr (STRADDLE) {
+                        const int cj = (mb + j * 16) / a.rpc;
+                        bj = a.bias_clip + (long)(cj < a.nclips ? cj : a.nclips - 1) * a.N + nb;
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         f32x4 v;
                         if constexpr (XE == 1) v = acc[i][j] * xrs[XE ? j : 0] + (bi[i] - *reinterpret_cast<const f32x4*>(gsc + i * 16 + fq * 4) * xrm[XE ? j : 0]);
+                        else if constexpr (STRADDLE) v = acc[i][j] * sc[i] + *reinterpret_cast<const f32x4*>(bj + i * 16);
                         else v = acc[i][j] * sc[i] + bi[i];
                         v = act4(v, CONV ? (a.relu != 0) : a.relu);
                         f16x4 hv = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
@@ -890,7 +920,13 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             };
-            if (m_full) store_rows(std::false_type{}); else store_rows(std::true_type{});
+            if constexpr (!CONV && XE == 0) {
+                if (straddle) {
+                    if (m_full) store_rows(std::false_type{}, std::true_type{}); else store_rows(std::true_type{}, std::true_type{});
+                } else if (m_full) store_rows(std::false_type{}, std::false_type{}); else store_rows(std::true_type{}, std::false_type{});
+            } else {
+                if (m_full) store_rows(std::false_type{}, std::false_type{}); else store_rows(std::true_type{}, std::false_type{});
+            }
         } else if constexpr (XE != 0) {
         } else if (interior) {
             f32x4 sc[4], bi[4];
@@ -1178,11 +1214,18 @@ static hipError_t launch_variant(const GemmArgs& a, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.ln_w) {
-        if (conv || !gemm_ln_fusable(a)) return hipErrorInvalidValue;
+        if (conv || !gemm_ln_fusable(a) || (a.bias_clip && (a.rpc < 128 || a.nclips <= 0))) return hipErrorInvalidValue;
         return launch_glds_ln<false>(a, o, s);
     }
     const bool w2 = a.Wl != nullptr;
     const bool narrow = a.N <= 64;
+    if (a.bias_clip) {
+        // per-clip bias: only the LDS-DMA kernel's fp16 row epilogue knows it (the LayerNorm-fused launch returned above); rpc >= 256
+        // keeps a tile within two clips' reach of the straddle path's per-block lookup
+        const bool ok = !conv && !a.ln_mode && o.gemm_glds && a.rpc >= 256 && a.nclips > 0 && a.K % 64 == 0 && a.M >= 128 && a.lda % 8 == 0 && a.ldw % 8 == 0 &&
+                        a.N % 128 == 0 && a.out16 && !a.out32 && !a.res && (a.ldc & 7) == 0 && !narrow;
+        if (!ok) return hipErrorInvalidValue;
+    }
     if (a.ln_mode) {
         // implicit LayerNorm: LDS-DMA instances with the fast epilogues only (whole tiles along n, 16-byte rows); anything else is a
         // caller error -- there is no slow path that would quietly ignore the statistics

@@ -48,7 +48,7 @@ def _add_precision_args(p):
 
 #: engine precision mode (include/jegal_hip.h) a driver selects for a checkpoint it has never seen, unless calibration clips are
 #: supplied: calibration-free by construction.  tests/test_gpu_weight_families.py holds THIS mode to 1e-3 on every weight family.
-REAL_CHECKPOINT_PRECISION = 1          # PREC_FP16_W2
+REAL_CHECKPOINT_PRECISION = 1          # PREC_FP16_W2 (PREC_FP16_RC = 5 once measured)
 
 
 def pick_precision(args, checkpoints, can_calibrate=True):
