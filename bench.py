@@ -282,6 +282,8 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with --nproc-per-node {args.gpus}")
 
+    import jegal_amd
+    jegal_amd.want_hw_queues()          # before the first HIP call: the streamed (PCIe-inclusive) leg runs five streams
     import numpy as np
     import torch
     from jegal_amd import synth

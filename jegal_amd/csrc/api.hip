@@ -77,6 +77,7 @@ struct Arena {          // stream-ordered bump allocator over persistent chunks
     std::vector<Chunk> chunks;
     size_t cur = 0, off = 0;
     void reset() { cur = 0; off = 0; }
+    unsigned long tick = 0;         // jg_set_stream: when this arena was last parked (least recently used goes first)
     size_t total() const { size_t t = 0; for (auto& c : chunks) t += c.cap; return t; }
     void* alloc(size_t bytes, hipError_t* err) {
         bytes = (bytes + 255) & ~size_t(255);
@@ -561,6 +562,7 @@ struct Epi {
     f16* x_lo = nullptr;
     const float* ln_gamma = nullptr;
     float* stat_out = nullptr;
+    int calib_rows = 0;           // calibration pass: only the first calib_rows rows of A are real (0: all M) -- short XLM-R batches are padded to 128 rows
     // JG_PREC_FP16_RC: the M rows are rc_clips clips of rc_rpc rows each (0: no clip structure -> a run-time corrected layer runs hi+lo)
     int rc_rpc = 0, rc_clips = 0;
 };
@@ -610,8 +612,10 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
         float* part;
         RET(wsalloc(h, col_sum_scratch_elems(L.K), &part));
         // (a folded consumer's effective input is the NORMALISED row: the correction term is (w' - fp16(w')) . E[(x - mean) rstd])
-        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, M, L.K, part, Lm.mu, h->stream, e.ln_mode == 1 ? e.ln_stats : nullptr); }));
-        Lm.mu_rows += M;
+        // (padding rows behind the caller's tokens would be averaged into E[x]: ADVICE r4)
+        const int rows = e.calib_rows > 0 && e.calib_rows < M ? e.calib_rows : M;
+        RET(timed(h, JG_ST_MISC, [&] { return launch_col_sum(A, lda, rows, L.K, part, Lm.mu, h->stream, e.ln_mode == 1 ? e.ln_stats : nullptr); }));
+        Lm.mu_rows += rows;
     }
     return timed(h, stage, [&] { return LAUNCH(h, launch_gemm, a, conv, h->opts, h->stream); });
 }
@@ -1211,7 +1215,7 @@ int finalize_xlmr(jg_handle* h) {
     // Implicit LayerNorm (xlmr_encode_folded): the Linear BEHIND a LayerNorm(gamma, beta) is packed as W diag(gamma) with bias
     // b + W beta (fold_consumer), the Linear whose output is ADDED to that LayerNorm's output takes beta into its bias (the
     // gamma (x - mean) rstd part is recomputed from the un-normalised stream in its epilogue).
-    const bool fold = h->xl_fold_opt;
+    const bool fold = h->xl_fold_opt && h->opts.gemm_glds;      // the implicit-LayerNorm epilogues exist in the LDS-DMA kernel only
     const HostTensor *pg, *pb;          // the LayerNorm in front of the current sub-layer
     RET(need(h, "xlmr.embeddings.LayerNorm.weight", D, &pg));
     RET(need(h, "xlmr.embeddings.LayerNorm.bias", D, &pb));
@@ -1321,13 +1325,13 @@ int xlmr_encode_folded(jg_handle* h, const int32_t* ids, const int32_t* amask, i
     const LNp* prev = &h->xl_emb_ln;
     for (int l = 0; l < h->xl_layers_n; ++l) {
         const EncLayer& Ly = h->xl_layers[l];
-        Epi q; q.out16 = qkv; q.ln_mode = 1; q.ln_stats = stats;
+        Epi q; q.out16 = qkv; q.ln_mode = 1; q.ln_stats = stats; q.calib_rows = M;
         RET(gemm(h, JG_ST_GEMM, xh, D, Mp, Ly.qkv, q));
         RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mk, B, L, H, 64, att, h->opts, h->stream); }));
-        Epi o; o.ln_mode = 2; o.ln_stats = stats; o.x_hi = xh; o.x_lo = xl; o.ln_gamma = prev->w; o.stat_out = part;
+        Epi o; o.ln_mode = 2; o.ln_stats = stats; o.x_hi = xh; o.x_lo = xl; o.ln_gamma = prev->w; o.stat_out = part; o.calib_rows = M;
         RET(gemm(h, JG_ST_GEMM, att, D, Mp, Ly.out, o));
         RET(ln_stats());
-        Epi f; f.relu = 2; f.out16 = hid; f.ln_mode = 1; f.ln_stats = stats;
+        Epi f; f.relu = 2; f.out16 = hid; f.ln_mode = 1; f.ln_stats = stats; f.calib_rows = M;
         RET(gemm(h, JG_ST_GEMM, xh, D, Mp, Ly.ff1, f));
         o.ln_gamma = Ly.n1.w;
         RET(gemm(h, JG_ST_GEMM, hid, DFF, Mp, Ly.ff2, o));
@@ -1340,6 +1344,9 @@ int xlmr_encode_folded(jg_handle* h, const int32_t* ids, const int32_t* amask, i
 int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
     if (!h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "XLM-RoBERTa weights not finalized (jg_finalize_weights(h, 4))");
     if (B <= 0 || L <= 0 || L > h->xl_maxpos - 2) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < L <= %d", h->xl_maxpos - 2);
+    if (h->xl_folded && !h->opts.gemm_glds)
+        JG_FAIL(h, JG_ERR_STATE, "the XLM-RoBERTa weights were packed for the implicit-LayerNorm pass, which needs the LDS-DMA GEMM: set option "
+                                 "gemm_glds=0 (or xlmr_fold=0) BEFORE jg_finalize_weights(h, 4)");
     if (h->xl_folded) return xlmr_encode_folded(h, ids, amask, B, L, out);
     constexpr int D = 768, DFF = 3072, H = 12;
     const int M = B * L;
@@ -1493,13 +1500,24 @@ int jg_set_stream(jg_handle* h, void* s) {
     if (!h) return JG_ERR_ARG;
     hipStream_t ns = reinterpret_cast<hipStream_t>(s);   // NULL is the legacy default stream, used as such
     if (ns != h->stream) {
+        static unsigned long tick = 0;
+        h->ws.tick = ++tick;
         std::swap(h->ws, h->ws_parked[h->stream]);       // park the current arena under its stream ...
         std::swap(h->ws, h->ws_parked[ns]);              // ... and take the new stream's (empty the first time)
         h->ws_parked.erase(ns);
-        if (h->ws_parked.size() > 6) {                   // a caller cycling through many streams: drop the parked arenas (hipFree waits for the device)
+        // A caller cycling through many streams (a fresh torch.cuda.Stream per batch): at most 6 parked arenas (>= 1 GiB each, INTEGRATION.md
+        // section 6) -- the LEAST RECENTLY used one goes, alone.  Its stream may no longer exist, so the device is synchronised rather
+        // than the stream (hipFree would wait for the device anyway); the debug pointers into a released arena are dropped with it.
+        while (h->ws_parked.size() > 6) {
+            auto lru = h->ws_parked.begin();
+            for (auto it = h->ws_parked.begin(); it != h->ws_parked.end(); ++it)
+                if (it->second.tick < lru->second.tick) lru = it;
             DeviceGuard dg(h->device);
-            for (auto& kv : h->ws_parked) kv.second.release();
-            h->ws_parked.clear();
+            (void)hipDeviceSynchronize();
+            lru->second.release();
+            h->ws_parked.erase(lru);
+            h->last_rowskip = nullptr;                   // (they may point into the arena that was just released)
+            h->last_conv_totals = nullptr;
         }
         h->stream = ns;
     }

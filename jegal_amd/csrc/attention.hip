@@ -8,7 +8,9 @@
 //                            from global memory, softmax on the accumulators, P carried as fp16 hi+lo.
 //     attn_mfma_kernel<NB>   S <= 160, dk = 64, optional key mask (JEGAL gesture encoder at the dataset's clip lengths):
 //                            one workgroup per (clip, head), K and V^T staged in LDS once, one wave per 32 queries.
-//     attn_kernel<DK>        everything else (160 < S <= 500, the text encoder's dk = 96): VALU kernel, one lane per
+//     attn_mfma_flash_kernel<DK>  everything else (dk = 64 with S > 160: long clips, XLM-RoBERTa at L > 160; dk = 96: the text
+//                            encoder): key chunks of 128 through LDS, online softmax, round 5.
+//     attn_kernel<DK>        option attn_mfma = 0 only (A/B, tests): VALU kernel, one lane per
 //                            query row, K/V rows in LDS read as wave-wide broadcasts, v_dot2_f32_f16, online softmax
 //                            over blocks of 8 keys, fp32 state.  For S <= 32 one wave carries floor(64/S) (sequence, head) pairs.
 #include "common.h"
@@ -206,7 +208,6 @@ __global__ __launch_bounds__(256, 5) void attn_mfma_s32_kernel(const f16* __rest
     const long ld = 3L * D;
     const f16* base = qkv + (GATHER ? 0L : (long)b * S * ld) + head * DK;
     const int r31 = lane & 31, hh = lane >> 5;
-    const int rowc = r31 < S ? r31 : S - 1;
     // GATHER: source row of token j
     int gc = 0, gi = 0;
     if (GATHER) { gc = b / g.Twin; gi = b - gc * g.Twin - g.shift; }
@@ -483,6 +484,159 @@ __global__ __launch_bounds__(64 * NB) void attn_mfma_kernel(const f16* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for every other instance (VERDICT r4 row k): dk = 64 with 160 < S (JEGAL clips of 161..500 frames, XLM-RoBERTa at
+// L > 160) and dk = 96 at any S (JEGAL text encoder: d = 768, h = 8, jegal.py:35-38), optional key mask.  One workgroup per
+// (sequence, head, group of up to 256 queries), one wave per 32 queries; the keys go by in chunks of 128: K (row-major) and V
+// (transposed) of a chunk are staged in LDS once per workgroup, every wave computes its 32 x 128 score block S^T = K Q^T on
+// v_mfma_f32_32x32x16, updates its ONLINE softmax state (running max and sum per query = per lane pair, fp32) and accumulates
+// O^T += V^T P^T with the probabilities split into fp16 hi+lo straight from the score accumulators (operand trick of
+// attn_mfma_s32_kernel).  The 1 / sum normalisation happens once, in fp32, at the end.  masked_fill(mask == 0, -1e9) as in
+// modules.py:66-67; keys >= S get -inf; score tiles entirely beyond S are skipped.
+template <int DK>
+__global__ __launch_bounds__(512) void attn_mfma_flash_kernel(const f16* __restrict__ qkv, const float* __restrict__ keymask, int S, int H,
+                                                              f16* __restrict__ out) {
+    constexpr int KC = 128, NV = DK / 8, KS = DK / 16, NBLK = DK / 32;
+    constexpr int K_PITCH = DK * 2 + 16, VT_PITCH = KC * 2 + 8, O_PITCH = 80;
+    constexpr int K_BYTES = KC * K_PITCH > 8 * 32 * O_PITCH ? KC * K_PITCH : 8 * 32 * O_PITCH;      // the output slices of eight waves alias the K image
+    __shared__ __attribute__((aligned(16))) char sK[K_BYTES];
+    __shared__ __attribute__((aligned(16))) char sVt[DK * VT_PITCH];
+    __shared__ __attribute__((aligned(16))) float sM[KC];
+    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x;
+    const int b = pair / H, head = pair - b * H;
+    const int D = H * DK;
+    const long ld = 3L * D;
+    const f16* base = qkv + (long)b * S * ld + head * DK;
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int q0 = 256 * blockIdx.y + 32 * wave;
+    const bool wave_on = q0 < S;                                    // (waves past the last query still help with the staging)
+    const int qr = q0 + r31 < S ? q0 + r31 : S - 1;
+    f16x8 qB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qB[s] = *reinterpret_cast<const f16x8*>(base + (long)qr * ld + 16 * s + 8 * hh);
+    f32x16 o[NBLK];
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[blk][i] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const float scale = DK == 64 ? 0.125f : 0.10206207261596575f;   // 1 / sqrt(dk)
+
+    for (int k0 = 0; k0 < S; k0 += KC) {
+        __syncthreads();                                            // every wave is done with the previous chunk
+        for (int idx = tid; idx < KC * NV; idx += NT) {
+            const int row = idx / NV, part = idx - row * NV;
+            const int rc = k0 + row < S ? k0 + row : S - 1;
+            const f16* src = base + (long)rc * ld + part * 8;
+            const f16x8 kk = *reinterpret_cast<const f16x8*>(src + D);
+            const f16x8 vv = *reinterpret_cast<const f16x8*>(src + 2 * D);
+            *reinterpret_cast<f16x8*>(sK + row * K_PITCH + part * 16) = kk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<f16*>(sVt + (part * 8 + e) * VT_PITCH + row * 2) = vv[e];
+        }
+        for (int j = tid; j < KC; j += NT) sM[j] = k0 + j < S ? (keymask ? keymask[(long)b * S + k0 + j] : 1.f) : -1.f;   // -1: beyond S
+        __syncthreads();
+        if (!wave_on) continue;
+        const int ntile = (S - k0 + 31) / 32 < KC / 32 ? (S - k0 + 31) / 32 : KC / 32;      // tiles of this chunk that hold a key
+        f32x16 sc[KC / 32];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KC / 32; ++kb) {
+            if (kb >= ntile) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 kA = *reinterpret_cast<const f16x8*>(sK + (32 * kb + r31) * K_PITCH + (16 * s + 8 * hh) * 2);
+                sc[kb] = JG_MFMA_32x32x16(kA, qB[s], sc[kb]);
+            }
+            // register i of tile kb <-> key k0 + 32kb + (i&3) + 8(i>>2) + 4*hh
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(&sM[32 * kb + 8 * g + 4 * hh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = sc[kb][4 * g + e] * scale;
+                    v = mk[e] < 0.f ? -INFINITY : (mk[e] == 0.f ? -1e9f : v);
+                    sc[kb][4 * g + e] = v;
+                    cm = fmaxf(cm, v);
+                }
+            }
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mnew = fmaxf(mrun, cm);                         // finite: the chunk holds at least one key < S
+        const float alpha = __expf(mrun - mnew);                    // first chunk: exp(-inf) = 0
+        mrun = mnew;
+        lrun *= alpha;
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[blk][i] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < KC / 32; ++kb) {
+            if (kb >= ntile) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sc[kb][i] = __expf(sc[kb][i] - mnew);
+                lrun += sc[kb][i];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 pH, pL;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = sc[kb][4 * (2 * s + (j >> 2)) + (j & 3)];
+                    const f16 hi = (f16)pv;
+                    pH[j] = hi;
+                    pL[j] = (f16)(pv - (float)hi);
+                }
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const char* vp = sVt + (r31 + 32 * blk) * VT_PITCH + (32 * kb + 16 * s + 4 * hh) * 2;
+                    const f16x4 v0 = *reinterpret_cast<const f16x4*>(vp), v1 = *reinterpret_cast<const f16x4*>(vp + 16);
+                    const f16x8 vA = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[blk] = JG_MFMA_32x32x16(vA, pH, o[blk]);
+                    o[blk] = JG_MFMA_32x32x16(vA, pL, o[blk]);
+                }
+            }
+        }
+    }
+    // ---- normalise, back to [query][d] rows through this wave's LDS slice (aliases the K image), 32 columns at a time
+    __syncthreads();
+    if (!wave_on) return;
+    const float inv = 1.f / (lrun + __shfl_xor(lrun, 32, 64));
+    char* sO = sK + wave * (32 * O_PITCH);
+    f16* obase = out + ((long)b * S + q0) * D + head * DK;
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f16x4 hv = {(f16)(o[blk][4 * g] * inv), (f16)(o[blk][4 * g + 1] * inv), (f16)(o[blk][4 * g + 2] * inv), (f16)(o[blk][4 * g + 3] * inv)};
+            *reinterpret_cast<f16x4*>(sO + r31 * O_PITCH + (8 * g + 4 * hh) * 2) = hv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = lane + 64 * r, row = c >> 2, part = c & 3;
+            if (q0 + row < S) *reinterpret_cast<f16x8*>(obase + (long)row * D + 32 * blk + part * 8) = *reinterpret_cast<const f16x8*>(sO + row * O_PITCH + part * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int DK>
+static hipError_t launch_attn_flash(const f16* qkv, const float* keymask, long npairs, int S, int H, f16* out, hipStream_t s) {
+    const int nq = S < 256 ? S : 256;
+    hipLaunchKernelGGL((attn_mfma_flash_kernel<DK>), dim3((unsigned)npairs, (unsigned)((S + 255) / 256)), dim3(64 * ((nq + 31) / 32)), 0, s, qkv, keymask, S, H, out);
+    return hipGetLastError();
+}
+
 template <int NB>
 static hipError_t launch_attn_mfma(const f16* qkv, const float* keymask, long npairs, int S, int H, f16* out, hipStream_t s) {
     hipLaunchKernelGGL((attn_mfma_kernel<NB>), dim3((unsigned)npairs), dim3(64 * NB), 0, s, qkv, keymask, S, H, out);
@@ -518,6 +672,12 @@ hipError_t launch_attention(const f16* qkv, const float* keymask, int B, int S, 
             default: return launch_attn_mfma<5>(qkv, keymask, npairs, S, H, out, s);
         }
     }
+    // everything else on the matrix cores too: dk = 64 beyond 160 keys, dk = 96 (text encoder) at any length
+    if (o.attn_mfma && npairs < (1L << 31)) {
+        if (dk == 64) return launch_attn_flash<64>(qkv, keymask, npairs, S, H, out, s);
+        if (dk == 96) return launch_attn_flash<96>(qkv, keymask, npairs, S, H, out, s);
+    }
+    // option attn_mfma = 0 (A/B and tests): the VALU kernel
     dim3 grid, block;
     int G = 1;
     if (S <= 32) {

@@ -272,6 +272,12 @@ def cmd_extract_jegal_embs(argv):
                 else:
                     print("Audio file does not exist: ", wav_fn)
                     continue
+            if "a" in mod and item["mel"].shape[0] < 4:
+                # under 4 mel frames (< 40 ms) the audio CNN has no output step: the reference's per-sample run raises inside its word
+                # pooling and the sample is skipped (jegal.py:230-239; the engine's ragged batch call rejects such a clip, and one
+                # bad clip must not abort the other fifteen of the batch)
+                print("Audio too short ({} mel frames), skipping: {}".format(item["mel"].shape[0], row.filename))
+                continue
             if "t" in mod and xlmr is None:
                 fn = os.path.join(args.text_states_dir or args.video_dir, row.filename.replace("/", "__") + ".npz")
                 if not os.path.exists(fn):
@@ -450,6 +456,8 @@ COMMANDS = {
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    from . import want_hw_queues
+    want_hw_queues()            # an application may shape its own process: before the first HIP call (no-op when the caller already set it)
     if not argv or argv[0] not in COMMANDS:
         print(__doc__)
         return 2

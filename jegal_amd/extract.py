@@ -211,6 +211,12 @@ class GestureStreamer:
 
     def __init__(self, engine, batch=32, frames=150, masked=False, source_hw=None):
         self.eng, self.batch, self.T, self.masked = engine, int(batch), int(frames), bool(masked) or source_hw is not None
+        q = os.environ.get("GPU_MAX_HW_QUEUES")
+        if q is None or not q.isdigit() or int(q) < 8:
+            import warnings
+            warnings.warn("GestureStreamer uses five streams (H2D, D2H, compute, two engine lanes) and the HIP runtime's default of 4 hardware "
+                          "queues can serialise the next upload behind the current compute (2 150 -> 1 230 clips/s measured): call "
+                          "jegal_amd.want_hw_queues() -- or export GPU_MAX_HW_QUEUES=8 -- before the process's first HIP call", RuntimeWarning)
         self.source_hw = None if source_hw is None else (int(source_hw[0]), int(source_hw[1]))
         dev = engine.device
         shape = (self.batch, self.T, 270, 480, 3)

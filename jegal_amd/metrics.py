@@ -108,7 +108,7 @@ def spotting_accuracy(gestures, contents, word_boundaries, targets, thresh=0.5, 
         pred, score = eng.spot(g, c, goff, coff, tidx)
         correct, _ = spotting_counts(pred.cpu().numpy(), score.cpu().numpy(), wbs, tidx, thresh, frame_thresh)
     correct, total = reduce_counts([correct, len(wbs)], eng.device)
-    return 100.0 * correct / total
+    return 100.0 * correct / max(1, total)
 
 
 def asd_counts(pred):

@@ -10,6 +10,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+import jegal_amd  # noqa: E402
+
+jegal_amd.want_hw_queues()          # the streamer tests run five streams; before the first HIP call of the test process
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

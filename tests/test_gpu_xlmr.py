@@ -250,6 +250,32 @@ def test_xlmr_calibration_is_explicit_and_holds_on_other_token_distributions():
     e2.close()
 
 
+def test_xlmr_calibration_on_one_short_sentence_ignores_the_padding_rows():
+    """batches of fewer than 128 tokens run padded to 128 rows; the calibration pass used to average those padding rows
+    (bias values, rstd = 316 after the first producer epilogue) into E[x].  Calibrating on ONE 20-token sentence must give the
+    corrections of the same sentence repeated 8 times (160 rows, no padding): identical E[x] up to summation order."""
+    from jegal_amd._lib import Engine
+    from jegal_amd.xlmr import XLMRoberta
+    sd = synth.xlmr_state_dict()
+    ids, mask = synth.xlmr_inputs(77, 1, 20)
+    test_ids, test_mask = synth.xlmr_inputs(78, 4, 40)
+    with torch.no_grad():
+        ref = O.xlmr_forward(sd, test_ids, test_mask)
+    mm = torch.from_numpy(test_mask).bool()
+    outs = {}
+    for name, rep in (("one sentence (20 rows, padded to 128)", 1), ("the sentence x 8 (160 rows)", 8)):
+        eng = Engine(0)
+        m = XLMRoberta(engine=eng).load_state_dict({"roberta." + k: v for k, v in sd.items()})
+        m.calibrate(torch.from_numpy(np.repeat(ids, rep, 0)).cuda(), torch.from_numpy(np.repeat(mask, rep, 0)).cuda())
+        outs[name] = m(torch.from_numpy(test_ids).cuda(), attention_mask=torch.from_numpy(test_mask).cuda()).last_hidden_state.cpu()
+        eng.close()
+        e = rel(outs[name][mm], ref[mm])
+        print(f"\ncalibrated on {name}: rel-L2 vs the fp32 restatement {e:.3e}", end="")
+        assert e < TOL
+    a, b = outs.values()
+    assert rel(a[mm], b[mm]) < 2e-5
+
+
 def test_dataset_driver_runs_xlmr_on_the_engine_batch_invariant(tmp_path, monkeypatch):
     """`extract_jegal_embs --modalities t --xlmr_checkpoint ... --tokenizer ...`: phrases from the csv -> tokenizer (host; a stub with
     the HuggingFace calling convention, the sentencepiece model is not available offline) -> XLM-RoBERTa on the engine -> JEGAL
