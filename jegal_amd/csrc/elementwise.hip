@@ -706,74 +706,83 @@ hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, 
 //     bias_clip[c][n] = bias[n] + sum_k lo[n][k] * mean_c[k],   mean_c = mean of a fixed sample of clip c's rows of A
 // (rows r = 0 .. rpc-1 relative to the clip's first row; sample: every row when rpc < 1024, otherwise the 16-row runs
 // (r >> 4) % 8 == 0 -- the error of a sampled mean is the row spread / sqrt(rows sampled), a few per cent of what the correction
-// removes).  Two launches: column sums per (clip, row split) in a fixed order, then the skinny product.  Deterministic.
-constexpr int RC_SPLITS = 8;
-__global__ __launch_bounds__(256) void rc_col_sum_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc, int K, float* __restrict__ part) {
-    __shared__ float red[256 * 8];
-    const int clip = blockIdx.x, sp = blockIdx.y, t = threadIdx.x;
-    const int tpr = K >> 3;                      // threads per row (16-byte column groups): 64 (K = 512) or 256 (K = 2048)
-    const int rows_par = 256 / tpr, rl = t / tpr, cg = t - rl * tpr;
+// removes).  Two launches: column means per clip (one workgroup per clip and 128-column slab, fixed summation order), then the skinny
+// product (one wave -- or, at K = 2048, one workgroup -- per output column).  Deterministic.
+__device__ __forceinline__ int rc_rows_sampled(int rpc) {
+    if (rpc < 1024) return rpc;
+    int cnt = 0;
+    for (int r0 = 0; r0 < rpc; r0 += 128) cnt += rpc - r0 < 16 ? rpc - r0 : 16;
+    return cnt;
+}
+__global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc, int K, float* __restrict__ mean) {
+    __shared__ float red[16][16 * 8 + 1];
+    const int clip = blockIdx.x, t = threadIdx.x;
+    const int cg = t & 15, rl = t >> 4;                         // 16 column groups of 8 (a 128-column slab) x 16 row lanes
+    const int n = blockIdx.y * 128 + cg * 8;
+    const int step = rpc < 1024 ? 16 : 128;                     // 16-row runs: every one, or every eighth
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // the sampled 16-row runs (every run, or every eighth) are dealt round-robin to the RC_SPLITS blocks of the clip
-    const int step = rpc < 1024 ? 16 : 128;
-    for (int r0 = sp * step; r0 < rpc; r0 += RC_SPLITS * step) {
-        for (int r = r0 + rl; r < r0 + 16 && r < rpc; r += rows_par) {
-            const long m = (long)clip * rpc + r;
-            const int n = cg * 8;
-            const f16* src = tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
-                                   : A + m * lda + n;
-            const f16x8 v = *reinterpret_cast<const f16x8*>(src);
+    for (int r = rl; r < rpc; r += step) {                      // row lane rl takes row rl of every sampled run
+        const long m = (long)clip * rpc + r;
+        const f16* src = tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
+                               : A + m * lda + n;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(src);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-        }
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[t * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
     __syncthreads();
-    if (rl == 0) {
+    if (t < 128) {
+        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s = 0.f;
-            for (int q = 0; q < rows_par; ++q) s += red[(q * tpr + cg) * 8 + e];
-            part[((long)clip * RC_SPLITS + sp) * K + cg * 8 + e] = s;
-        }
+        for (int q = 0; q < 16; ++q) s += red[q][t];
+        mean[(long)clip * K + blockIdx.y * 128 + t] = s / (float)rc_rows_sampled(rpc);
     }
 }
-// out[c][n] = bias[n] + (1 / rows sampled) sum_k lo[n][k] * (sum over the splits of part[c][.][k]);  block = 32 clips x 8 outputs
-__global__ __launch_bounds__(256) void rc_gemv_kernel(const float* __restrict__ part, const f16* __restrict__ lo, const float* __restrict__ bias,
-                                                      int nclips, int rpc, int N, int K, float* __restrict__ out) {
-    const int nl = threadIdx.x & 7, cl = threadIdx.x >> 3;
-    const int n = blockIdx.x * 8 + nl, c = blockIdx.y * 32 + cl;
-    if (n >= N || c >= nclips) return;
-    int cnt = 0;
-    if (rpc < 1024) cnt = rpc;
-    else
-        for (int r0 = 0; r0 < rpc; r0 += 128) cnt += rpc - r0 < 16 ? rpc - r0 : 16;
-    const float* p = part + (long)c * RC_SPLITS * K;
-    const f16* w = lo + (long)n * K;
-    float acc = 0.f;
-    for (int k = 0; k < K; k += 8) {
-        const f16x8 wv = *reinterpret_cast<const f16x8*>(w + k);
-        f32x4 s0 = *reinterpret_cast<const f32x4*>(p + k), s1 = *reinterpret_cast<const f32x4*>(p + k + 4);
+// out[c][n] = bias[n] + sum_k lo[n][k] * mean[c][k].  K / 8 threads share one output column (64 = one wave at K = 512, the whole
+// workgroup at K = 2048); each holds its 8 weights and walks the clips.
+__global__ __launch_bounds__(256) void rc_gemv_kernel(const float* __restrict__ mean, const f16* __restrict__ lo, const float* __restrict__ bias,
+                                                      int nclips, int N, int K, float* __restrict__ out) {
+    __shared__ float red[4][32];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tpn = K >> 3;                                     // threads per output column
+    const int npb = 256 / tpn;                                  // columns per workgroup: 4 or 1
+    const int n = blockIdx.x * npb + (npb == 4 ? wave : 0);
+    const int k0 = (npb == 4 ? lane : t) * 8;
+    const f16x8 wv = *reinterpret_cast<const f16x8*>(lo + (long)n * K + k0);
+    float w[8];
 #pragma unroll
-        for (int q = 1; q < RC_SPLITS; ++q) {
-            s0 += *reinterpret_cast<const f32x4*>(p + (long)q * K + k);
-            s1 += *reinterpret_cast<const f32x4*>(p + (long)q * K + k + 4);
+    for (int e = 0; e < 8; ++e) w[e] = (float)wv[e];
+    for (int c0 = 0; c0 < nclips; c0 += 32) {
+        const int nc = nclips - c0 < 32 ? nclips - c0 : 32;
+        float mine = 0.f;                                       // lane c (< nc) ends up with clip c0 + c's sum over this wave's k
+        for (int c = 0; c < nc; ++c) {
+            const float* p = mean + (long)(c0 + c) * K + k0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+            float v = w[0] * a.x + w[1] * a.y + w[2] * a.z + w[3] * a.w + w[4] * b.x + w[5] * b.y + w[6] * b.z + w[7] * b.w;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == c) mine = v;
         }
-        acc += (float)wv[0] * s0.x + (float)wv[1] * s0.y + (float)wv[2] * s0.z + (float)wv[3] * s0.w + (float)wv[4] * s1.x + (float)wv[5] * s1.y +
-               (float)wv[6] * s1.z + (float)wv[7] * s1.w;
+        if (npb == 4) {
+            if (lane < nc) out[(long)(c0 + lane) * N + n] = (bias ? bias[n] : 0.f) + mine;
+        } else {
+            __syncthreads();
+            if (lane < 32) red[wave][lane] = mine;
+            __syncthreads();
+            if (t < nc) out[(long)(c0 + t) * N + n] = (bias ? bias[n] : 0.f) + ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+        }
     }
-    out[(long)c * N + n] = (bias ? bias[n] : 0.f) + acc / (float)cnt;
 }
 
-size_t rc_scratch_elems(int nclips, int K) { return (size_t)nclips * RC_SPLITS * K; }
+size_t rc_scratch_elems(int nclips, int K) { return (size_t)nclips * K; }
 
 hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const f16* lo, const float* bias, int N, int K, float* scratch,
                           float* out, hipStream_t s) {
     if (nclips <= 0 || rpc <= 0) return hipSuccess;
-    if ((K != 512 && K != 2048) || (tiled && K != 512) || (N & 7)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rc_col_sum_kernel, dim3(nclips, RC_SPLITS), dim3(256), 0, s, A, lda, tiled, rpc, K, scratch);
-    hipLaunchKernelGGL(rc_gemv_kernel, dim3(N / 8, (nclips + 31) / 32), dim3(256), 0, s, scratch, lo, bias, nclips, rpc, N, K, out);
+    if ((K != 512 && K != 2048) || (tiled && K != 512) || (N & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rc_col_mean_kernel, dim3(nclips, K / 128), dim3(256), 0, s, A, lda, tiled, rpc, K, scratch);
+    hipLaunchKernelGGL(rc_gemv_kernel, dim3(K == 512 ? N / 4 : N), dim3(256), 0, s, scratch, lo, bias, nclips, N, K, out);
     return hipGetLastError();
 }
 

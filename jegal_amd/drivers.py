@@ -5,6 +5,7 @@
     python -m jegal_amd.drivers evaluate_retrieval --path D  # evaluation/evaluate_retrieval.py
     python -m jegal_amd.drivers evaluate_spotting  --path D  # evaluation/evaluate_spotting.py
     python -m jegal_amd.drivers evaluate_asd --path D --file avs_asd.csv   # evaluation/evaluate_asd.py
+    python -m jegal_amd.drivers inference_embs ...            # inference_embs.py (single clip -> <fname>.pkl)
 
 Same flags, file naming and on-disk formats as the reference.  What is upstream of the hot path is
 NOT rebuilt: video decoding / mediapipe masking (the drivers read already masked 270x480 crops as
@@ -452,6 +453,121 @@ COMMANDS = {
     "evaluate_spotting": cmd_evaluate_spotting,
     "evaluate_asd": cmd_evaluate_asd,
 }
+COMMANDS["inference_embs"] = lambda argv: cmd_inference_embs(argv)      # (defined below)
+
+
+# --------------------------------------------------------------------------- inference_embs
+def cmd_inference_embs(argv):
+    """inference_embs.py (the reference's single-clip driver, :526-646 + the __main__ checks :648-685): one clip in, one
+    ``<res_dir>/<fname>.pkl`` = {"gesture_emb" (T,512) | None, "content_emb" (W,512) | None, "info": {fname, word_boundaries, text}} out.
+
+    Upstream of the hot path and NOT rebuilt: video decoding, the mediapipe face mesh and WhisperX.  So --video_path is a ``.npy``:
+    the decoded frames (T,H,W,3) uint8 at source resolution with --mask_y (per frame: last blanked source row = chin y2 + 15, or -1
+    for "no face", inference_embs.py:264-270; a ``.npy`` of T ints or one int) -- the face rectangle, the cv2-style resize to
+    270 x 480, /255 and the +-12 frame edge padding then run on the GPU -- or already masked (T,270,480,3) crops (no --mask_y).
+    --audio_path is a 16 kHz mono ``.wav`` (log-mel on the GPU); --text_path the reference's text-file grammar (:288-377); word
+    boundaries must come from it (the WhisperX fallback of :589-601 is upstream).  Text needs XLM-RoBERTa states: --xlmr_checkpoint +
+    --tokenizer (encoder on the engine, models/jegal.py:116-129) or --text_states (.npz: states, mask, ids, offsets).
+
+    All seven --modalities work (the reference unpacks two return values and indexes word_boundaries[0] unconditionally, so only
+    'vta' / 'vt' / 'va' survive there): outputs follow JEGAL.forward_inference's own return convention (:377-415)."""
+    from . import audio as jaudio
+    from . import extract
+    p = argparse.ArgumentParser(prog="inference_embs")
+    p.add_argument("--checkpoint_path_gestsync", required=True)
+    p.add_argument("--checkpoint_path_jegal", required=True)
+    p.add_argument("--modalities", default="vta", choices=["vta", "vt", "va", "ta", "v", "t", "a"])
+    p.add_argument("--video_path", default=None, help=".npy of frames: (T,H,W,3) uint8 source frames (with --mask_y) or masked (T,270,480,3) crops")
+    p.add_argument("--mask_y", default=None, help=".npy of T ints or one int: last blanked source row per frame (chin y2 + 15; -1 = no face)")
+    p.add_argument("--text_path", default=None)
+    p.add_argument("--audio_path", default=None)
+    p.add_argument("--res_dir", required=True)
+    p.add_argument("--text_states", default=None, help="precomputed XLM-RoBERTa states (.npz: states, mask, ids, offsets) for --text_path's words")
+    p.add_argument("--xlmr_checkpoint", default=None)
+    p.add_argument("--tokenizer", default=None)
+    _add_precision_args(p)
+    args = p.parse_args(argv)
+    mod = args.modalities
+    for m, arg in (("v", "video_path"), ("a", "audio_path")):                # inference_embs.py:650-664
+        if m in mod and getattr(args, arg) is None:
+            raise ValueError(f"--{arg} must be specified when modality '{m}' is used.")
+    if "t" in mod and args.text_path is None and args.audio_path is None:
+        raise ValueError("For modality 't', you must specify either --text_path or --audio_path (since text can be extracted from audio).")
+    if mod != "v" and args.text_path is None:
+        raise SystemExit("word boundaries come from --text_path here (the reference's WhisperX fallback, inference_embs.py:589-601, is upstream of the hot path)")
+    if "t" in mod and not (args.text_states or (args.xlmr_checkpoint and args.tokenizer)):
+        raise SystemExit("modality 't' needs --text_states or --xlmr_checkpoint with --tokenizer")
+    ns = argparse.Namespace(checkpoint_path_gestsync=args.checkpoint_path_gestsync, checkpoint_path=args.checkpoint_path_jegal,
+                            precision=args.precision, calibrate_frames=args.calibrate_frames)
+    eng, gs, jg = _models(ns, need_gestsync="v" in mod, need_jegal=True)
+    os.makedirs(args.res_dir, exist_ok=True)
+    vis = mask = text = audio = am = wbs = None
+    fname = None
+    text_strs = None
+    if args.video_path is not None and "v" in mod:
+        frames = np.load(args.video_path)
+        if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
+            raise ValueError("--video_path must hold (T,H,W,3) uint8 frames")
+        if args.mask_y is not None:
+            my = np.load(args.mask_y) if args.mask_y.endswith(".npy") else np.full(frames.shape[0], int(args.mask_y))
+            crops = eng.mask_resize(torch.from_numpy(frames), np.asarray(my, np.int32).reshape(-1))
+        else:
+            if tuple(frames.shape[1:3]) != (270, 480):
+                raise ValueError("frames that are not 270x480 need --mask_y (source-resolution path)")
+            crops = torch.from_numpy(frames).to(eng.device)
+        print("Input masked frames: ", tuple(crops.shape))
+        print("Extracting pre-trained GestSync features...")
+        vis = gs.extract_clip_feats(crops)                                   # (1,T,1024): get_gestsync_feats (:476-522)
+        mask = torch.ones(vis.shape[:2], device=vis.device)
+        fname = os.path.basename(args.video_path).split(".")[0]
+        print("Input visual features: ", tuple(vis.shape))
+    if args.text_path is not None:
+        text_strs, wbs = extract.load_text(args.text_path)
+        if fname is None:
+            fname = os.path.basename(args.text_path).split(".")[0]
+    if args.audio_path is not None and "a" in mod:
+        print("Loading audio...")
+        wav = torch.from_numpy(np.asarray(jaudio.load_wav(args.audio_path)).astype(np.float32))
+        audio = jaudio.wav2filterbanks(wav[None].to(eng.device), engine=eng)[0]       # load_audio (:440-475)
+        print("Input audio mel: ", tuple(audio.shape))
+        am = torch.ones((1, audio.shape[1] // 4), device=eng.device)
+    if fname is None and args.audio_path is not None:
+        fname = os.path.basename(args.audio_path).split(".")[0]
+    if "t" in mod:
+        if args.text_states:
+            st, tm, ids, offs = _load_text_pack(args.text_states)
+            st, tm, ids, offs = (np.asarray(x) for x in (st, tm, ids, offs))
+            if st.ndim == 2:
+                st, tm, ids, offs = st[None], tm[None], ids[None], offs[None]
+            text = (torch.from_numpy(st.astype(np.float32)), torch.from_numpy(tm), [text_strs[0].split(" ")], ids, offs)
+        else:
+            from .xlmr import roberta_embeddings
+            text = roberta_embeddings(_load_xlmr(eng, args.xlmr_checkpoint), _load_tokenizer(args.tokenizer), text_strs)
+    print("Extracting JEGAL embeddings...")
+    print("------------------------------------------------")
+    out = jg.forward_inference(visual_feats=vis, visual_mask=mask, text=text, audio=audio, audio_mask=am,
+                               word_boundaries=wbs if mod != "v" else None)
+    gesture = content = None
+    if vis is not None and (text is not None or audio is not None):
+        gesture, content = out
+    elif vis is not None:
+        gesture = out
+    else:
+        content = out
+    if gesture is not None:
+        gesture = eng.l2norm(gesture[0]).cpu().numpy()                       # F.normalize(p=2, dim=-1), [0], .cpu().numpy() (:629-637)
+        print("Extracted gesture embeddings: ", gesture.shape)
+    if content is not None:
+        content = eng.l2norm(content[0]).cpu().numpy()
+        print("Extracted content embeddings: ", content.shape)
+    print("------------------------------------------------")
+    feat = {"gesture_emb": gesture, "content_emb": content,
+            "info": {"fname": fname, "word_boundaries": None if wbs is None else wbs[0], "text": None if text_strs is None else text_strs[0]}}
+    output_fname = os.path.join(args.res_dir, fname + ".pkl")
+    with open(output_fname, "wb") as f:
+        pickle.dump(feat, f)
+    print("Saved the embeddings: ", output_fname)
+    return 0
 
 
 def main(argv=None):
