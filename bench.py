@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default), 4 bf16 (reported mode: outside the 1e-3 contract)")
+    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
@@ -332,12 +332,13 @@ def main():
         jdist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(n, src=None):
+    def timed_loop(n, src=None, engine=None):
         src = frames if src is None else src
+        engine = eng if engine is None else engine
         sync_all()
         t0 = time.perf_counter()
         for _ in range(n):
-            eng.extract_gesture(src, out)
+            engine.extract_gesture(src, out)
         sync_all()
         mine = time.perf_counter() - t0
         tmax = torch.tensor([mine], dtype=torch.float64, device=dev)
@@ -531,6 +532,38 @@ def main():
                 assert np.array_equal(emb_s, out.cpu().numpy()), "source-resolution upload differs from load_rgb_masked_frames + the resident path"
                 extras["pcie_source_hw"] = [SH, SW]
                 del st, crops, src
+        # The same timed loop in the other precision treatments a driver can select: `value` is the default mode
+        # (bias corrections from a calibration pass: what the seeded weights get); a checkpoint the drivers have never seen gets a
+        # calibration-FREE mode -- 5 = run-time corrected (per-clip E[x] from the clip's own rows), 1 = hi+lo Linear weights.  Fresh
+        # engine per mode (the precision is fixed at finalize), same inputs, same number of steps, stage table from bracketed steps.
+        if world == 1:
+            extras["precision_modes"] = {}
+            for mode, name in ((5, "rc"), (1, "w2")):
+                if mode == args.precision:
+                    continue
+                e2 = Engine(local_dev, precision=mode)
+                e2.set_chunk(args.chunk)
+                for o in args.opt:
+                    k, v = o.split("=")
+                    e2.set_option(k, int(v))
+                GestSync(engine=e2).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+                JEGAL(engine=e2).load_state_dict(synth.jegal_state_dict())
+                for _ in range(max(3, args.warmup)):
+                    e2.extract_gesture(frames, out)
+                t2 = timed_loop(args.steps, engine=e2)
+                assert torch.isfinite(out).all()
+                e2.set_option("dual_stream", 0)
+                e2.profile(True)
+                for _ in range(2):
+                    e2.extract_gesture(frames, out)
+                e2.profile_reset()
+                for _ in range(nprof):
+                    e2.extract_gesture(frames, out)
+                p2 = e2.profile_get()
+                e2.profile(False)
+                extras["precision_modes"][name] = {"precision_mode": mode, "value": args.clips * args.steps / t2, "ms_per_step": t2 / args.steps * 1e3,
+                                                   "stage_ms_per_step": {k: round(v[0] / nprof, 3) for k, v in p2.items()}}
+                e2.close()
     jdist.barrier()
 
     if rank == 0:
@@ -619,6 +652,12 @@ def main():
             res["spotting_config5"] = extras["spotting"]
             if "config3" in extras:
                 res["config3"] = extras["config3"]
+            if extras.get("precision_modes"):
+                res["precision_modes"] = dict(extras["precision_modes"],
+                                              what="the SAME timed loop (same clips, steps, two lanes) in the calibration-free precision treatments: rc = "
+                                                   "JG_PREC_FP16_RC (per-clip run-time correction; what the CLI drivers select for a checkpoint they have "
+                                                   "never seen), w2 = JG_PREC_FP16_W2 (hi+lo Linear weights); `value` above is the default mode "
+                                                   "(JG_PREC_FP16_BC, corrections from a calibration pass)")
             if "pcie_clips_per_s" in extras:
                 res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",
                                          "what": "host-resident clips -> pinned buffers -> H2D under compute -> embeddings back on the host (GestureStreamer); never `value`"}

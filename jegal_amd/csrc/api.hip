@@ -19,7 +19,7 @@ namespace {
 // ---- dispatch between the two kernel builds.  LAUNCH(h, launch_x, args...) calls launch_x of the fp16 build or bf::launch_x of
 // the bf16 build (precision mode JG_PREC_BF16): same argument lists, the 16-bit pointers and the structs that carry them are
 // layout-identical in both builds and simply re-typed.
-inline const bf::f16* to_bf(const f16* p) { return reinterpret_cast<const bf::f16*>(p); }
+[[maybe_unused]] inline const bf::f16* to_bf(const f16* p) { return reinterpret_cast<const bf::f16*>(p); }
 inline bf::f16* to_bf(f16* p) { return reinterpret_cast<bf::f16*>(p); }
 inline const bf::GemmArgs& to_bf(const GemmArgs& a) { return reinterpret_cast<const bf::GemmArgs&>(a); }
 inline const bf::EngineOpts& to_bf(const EngineOpts& o) { return reinterpret_cast<const bf::EngineOpts&>(o); }
@@ -93,7 +93,7 @@ struct Arena {          // stream-ordered bump allocator over persistent chunks
         cur = chunks.size() - 1; off = bytes;
         return p;
     }
-    void release() { for (auto& c : chunks) hipFree(c.p); chunks.clear(); reset(); }
+    void release() { for (auto& c : chunks) (void)hipFree(c.p); chunks.clear(); reset(); }
 };
 
 struct ProfRec { int stage; hipEvent_t e0, e1; };
@@ -112,6 +112,7 @@ struct jg_handle {
     std::vector<Lin*> bc_layers;   // bias-corrected layers of both models (entries of a model are dropped on its re-finalize)
     int chunk = 32;                // clips per GestSync pass: ~14 GB of workspace per lane at 150 frames; 288 GB of HBM make the whole BASELINE batch one pass
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
+    bool stream8 = true;           // option "stream8": the fused transformer's token stream carries the 8-bit correction plane (0: fp16 plane alone)
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     f16* gs_qpe = nullptr;         // [21][1536]: layer-0 W_qkv pe[j] + b (Qkv0); recomputed when weights or bias corrections change
@@ -835,7 +836,8 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
         auto proj_ln = [&](const f16* A, long lda, const Lin& W, const LNp& ln) -> int {
             Epi r;
             if (tiled) {
-                r.res16 = x16; r.res8 = d8; r.out16 = x16; r.out8 = d8; r.ln = &ln; r.ln_flavour = LN_STD;
+                r.res16 = x16; r.out16 = x16; r.ln = &ln; r.ln_flavour = LN_STD;
+                if (h->stream8) { r.res8 = d8; r.out8 = d8; }
                 r.rc_rpc = rc_rpc; r.rc_clips = rc_clips;
                 return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
             }
@@ -1086,7 +1088,7 @@ int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T, in
     HIPCHK(h, hipMalloc(&feats, (size_t)B * T * 1024 * sizeof(float)));
     HIPCHK(h, hipMalloc(&emb, (size_t)B * T * 512 * sizeof(float)));
     for (Lin* L : h->bc_layers) {
-        if (hipMemsetAsync(L->mu, 0, sizeof(float) * L->K, h->stream) != hipSuccess) { hipFree(feats); hipFree(emb); if (own) hipFree(own); JG_FAIL(h, JG_ERR_HIP, "hipMemsetAsync(mu) failed"); }
+        if (hipMemsetAsync(L->mu, 0, sizeof(float) * L->K, h->stream) != hipSuccess) { (void)hipFree(feats); (void)hipFree(emb); if (own) (void)hipFree(own); JG_FAIL(h, JG_ERR_HIP, "hipMemsetAsync(mu) failed"); }
         L->mu_rows = 0;
     }
     h->calib = true;
@@ -1109,10 +1111,10 @@ int calibrate_impl(jg_handle* h, const void* frames, int dtype, int B, int T, in
     }
     h->calib = false;
     if (rc == JG_OK) rc = apply_bias_corrections(h, models);
-    hipStreamSynchronize(h->stream);
-    hipFree(feats);
-    hipFree(emb);
-    if (own) hipFree(own);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(feats);
+    (void)hipFree(emb);
+    if (own) (void)hipFree(own);
     return rc;
 }
 
@@ -1474,19 +1476,19 @@ int jg_destroy(jg_handle* h) {
     if (!h) return JG_OK;
     {
         DeviceGuard dg(h->device);
-        hipDeviceSynchronize();
-        for (auto& r : h->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
-        for (void* p : h->wallocs_gs) hipFree(p);
-        for (void* p : h->wallocs_jg) hipFree(p);
-        for (void* p : h->wallocs_xl) hipFree(p);
-        if (h->feats) hipFree(h->feats);
-        if (h->gs_qpe) hipFree(h->gs_qpe);
+        (void)hipDeviceSynchronize();
+        for (auto& r : h->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        for (void* p : h->wallocs_gs) (void)hipFree(p);
+        for (void* p : h->wallocs_jg) (void)hipFree(p);
+        for (void* p : h->wallocs_xl) (void)hipFree(p);
+        if (h->feats) (void)hipFree(h->feats);
+        if (h->gs_qpe) (void)hipFree(h->gs_qpe);
         h->ws.release();
         for (auto& kv : h->ws_parked) kv.second.release();
-        for (int l = 0; l < jg_handle::MAX_LANES; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) hipStreamDestroy(h->lane_stream[l]); }
-        for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) hipEventDestroy(h->lane_ev[e]);
+        for (int l = 0; l < jg_handle::MAX_LANES; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]); }
+        for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) (void)hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
-        if (h->own_stream) hipStreamDestroy(h->own_stream);
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     }
     delete h;
     return JG_OK;
@@ -1545,6 +1547,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     EngineOpts& o = h->opts;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "stream8")) { h->stream8 = value != 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_mfma16")) { o.conv1_mfma16 = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
@@ -1763,8 +1766,8 @@ int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int 
     HIPCHK(h, hipEventSynchronize(e1));
     float t = 0.f;
     HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *ms = t / iters;
     return JG_OK;
 }
@@ -1935,8 +1938,8 @@ static int prof_collect(jg_handle* h) {
         HIPCHK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
         h->prof_ms[r.stage] += ms;
         h->prof_n[r.stage] += 1;
-        hipEventDestroy(r.e0);
-        hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
     }
     h->recs.clear();
     return JG_OK;

@@ -33,6 +33,16 @@
 // Neighbouring workgroups work on the strips of one position at the same time, so its 5 frames
 // (1.9 MB) stay in the XCD L2s; a frame is re-read for 5 positions.
 #include "common.h"
+
+// Diagnostic build only (-DJG_CLOCK_STAMPS, tools/inkernel_clock.py; MI355X_MICROARCH.md "DVFS give-back" item 6): MFMA wave 0 of every
+// workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) around its main loop; the differences go to a buffer of
+// their own that no kernel reads.  In the product build no stamp executes.
+#ifdef JG_CLOCK_STAMPS
+__device__ unsigned long long jg_clock_stamps_conv1[2 * 1024];
+extern "C" int jg_clock_read_conv1(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jg_clock_stamps_conv1), sizeof(unsigned long long) * (n < 2048 ? n : 2048)) == hipSuccess ? 0 : 1;
+}
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -591,6 +601,9 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 ++tli;
             }
         };
+#ifdef JG_CLOCK_STAMPS
+        const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int t = 0;; ++t) {
             mark();
             __syncthreads();
@@ -669,6 +682,12 @@ __global__ __launch_bounds__(512, 2) void conv1_direct_kernel(Conv1Args a) {
                 epilogue(acc, mb0 + 2 * q);
             }
         }
+#ifdef JG_CLOCK_STAMPS
+        if (wave == 0 && lane == 0 && blockIdx.x < 1024) {
+            jg_clock_stamps_conv1[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck0;
+            jg_clock_stamps_conv1[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+#endif
         return;
     }
     const int r = lane & 31, h = lane >> 5;

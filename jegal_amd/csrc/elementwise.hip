@@ -721,11 +721,22 @@ __global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict_
     const int n = blockIdx.y * 128 + cg * 8;
     const int step = rpc < 1024 ? 16 : 128;                     // 16-row runs: every one, or every eighth
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = rl; r < rpc; r += step) {                      // row lane rl takes row rl of every sampled run
+    auto row_ptr = [&](int r) -> const f16* {
         const long m = (long)clip * rpc + r;
-        const f16* src = tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
-                               : A + m * lda + n;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(src);
+        return tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
+                     : A + m * lda + n;
+    };
+    // row lane rl takes row rl of every sampled run; four loads in flight per thread (the loop is a latency chain otherwise), summed
+    // in row order whatever the grouping
+    int r = rl;
+    for (; r + 3 * step < rpc; r += 4 * step) {
+        const f16x8 v0 = *reinterpret_cast<const f16x8*>(row_ptr(r)), v1 = *reinterpret_cast<const f16x8*>(row_ptr(r + step));
+        const f16x8 v2 = *reinterpret_cast<const f16x8*>(row_ptr(r + 2 * step)), v3 = *reinterpret_cast<const f16x8*>(row_ptr(r + 3 * step));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (((acc[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
+    }
+    for (; r < rpc; r += step) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(row_ptr(r));
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
     }

@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 // Rows beyond M / N are clamped to the last valid row (their results are never stored).
 // Workgroups that share an activation row panel (the N tiles of one M tile) are remapped onto one
 // XCD so the panel is fetched into that L2 once.
+// Diagnostic build only (-DJG_CLOCK_STAMPS, see conv1.hip): wave 0 of every workgroup stamps both clocks around its persistent loop.
+#if defined(JG_CLOCK_STAMPS) && !defined(JG_BF16)
+__device__ unsigned long long jg_clock_stamps_gemm[2 * 1024];
+extern "C" int jg_clock_read_gemm(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jg_clock_stamps_gemm), sizeof(unsigned long long) * (n < 2048 ? n : 2048)) == hipSuccess ? 0 : 1;
+}
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -463,7 +470,11 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         // read-once stream: nontemporal, so it does not push the weights out of L2
         const u32x2 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp)), r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 256));
         const u32x2 r2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 512)), r3 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 768));
-        const u32x4 dq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res8 + d8t_off(tm0) + j * 1024));
+        // res8 == nullptr (option stream8 = 0, round 5): the token stream is the fp16 plane alone -- in a post-norm transformer the
+        // LayerNorm output is rounded to fp16 as the next GEMM's operand anyway, and carrying the residual at that precision costs
+        // 1-5 % of the feature error (oracle/precision_families.py) for a third fewer stream bytes and no codec arithmetic
+        u32x4 dq = {0u, 0u, 0u, 0u};
+        if (a.res8) dq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.res8 + d8t_off(tm0) + j * 1024));
         acc[0][j] = f32x4{asf(r0.x), asf(r0.y), asf(r3.x), asf(r3.y)};
         acc[1][j] = f32x4{asf(r1.x), asf(r1.y), 0.f, 0.f};
         acc[2][j] = f32x4{asf(r2.x), asf(r2.y), 0.f, 0.f};
@@ -474,6 +485,9 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         for (int j = 0; j < MI; ++j) load_stream(m0, j);
     }
     int pending = 0;           // the k-tile-0 DMA of this tile is older than exactly `pending` epilogue stores (0: unknown)
+#if defined(JG_CLOCK_STAMPS) && !defined(JG_BF16)
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     while (true) {
         // The first k-tile of this tile was issued BEFORE the previous tile's epilogue stores, so it can be
         // retired with a counted wait that leaves those stores in flight: the store burst (and its HBM
@@ -482,6 +496,7 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
             case 8: wait_vmcnt<8>(); break;
             case 16: wait_vmcnt<16>(); break;
             case 32: wait_vmcnt<32>(); break;
+            case 48: wait_vmcnt<48>(); break;
             case 60: wait_vmcnt<60>(); break;
             default: wait_vmcnt<0>(); break;
         }
@@ -701,7 +716,7 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
             __syncthreads();
             mark();     // 2 (LNF): row statistics done, the store / reload phase starts
             f16* o16 = a.out16 + x16t_off(cm0);
-            signed char* o8 = a.out8 + d8t_off(cm0);
+            signed char* o8 = a.out8 ? a.out8 + d8t_off(cm0) : nullptr;
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 if (j == JD) {
@@ -721,16 +736,18 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
                                     *reinterpret_cast<const f32x4*>(lnp + 2 * BN + ncol + i * 16);
                     const f16x4 hv = {(f16)y.x, (f16)y.y, (f16)y.z, (f16)y.w};
                     *reinterpret_cast<f16x4*>(o16 + j * 1024 + i * 256) = hv;
-                    const unsigned dw = res_enc4(y.x, y.y, y.z, y.w, hv[0], hv[1], hv[2], hv[3]);
-                    if (i == 0) dq.x = dw; else if (i == 1) dq.y = dw; else if (i == 2) dq.z = dw; else dq.w = dw;
+                    if (o8) {
+                        const unsigned dw = res_enc4(y.x, y.y, y.z, y.w, hv[0], hv[1], hv[2], hv[3]);
+                        if (i == 0) dq.x = dw; else if (i == 1) dq.y = dw; else if (i == 2) dq.z = dw; else dq.w = dw;
+                    }
                 }
-                *reinterpret_cast<uint4*>(o8 + j * 1024) = dq;
+                if (o8) *reinterpret_cast<uint4*>(o8 + j * 1024) = dq;
                 if (nbid >= 0) load_stream(m0, j);                        // m0 is already the next tile's
             }
             mark();     // 3: epilogue issued
             if (nbid < 0) break;
             // the loop-top barrier fences red[] / lnp[] against the next tile's k-tile 1 (staged after it)
-            pending = counted_ok ? (MI - JD) * 10 : 0;
+            pending = counted_ok ? (MI - JD) * (o8 ? 10 : 8) : 0;
             continue;
         }
         // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile.
@@ -1005,6 +1022,12 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         if (nbid < 0) break;
         pending = !(interior && m_full && counted_ok) || xdone ? 0 : rows16 ? 2 * MI : (a.out32 ? 4 * MI : 0) + (a.out16 ? 4 * MI : 0);
     }
+#if defined(JG_CLOCK_STAMPS) && !defined(JG_BF16)
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) {
+        jg_clock_stamps_gemm[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck0;
+        jg_clock_stamps_gemm[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
 }
 
 // ---- host side.  Every tuning switch and per-device resource lives in the caller's EngineOpts (one per jg_handle):
@@ -1124,7 +1147,7 @@ static hipError_t launch_glds_ln(const GemmArgs& a, const EngineOpts& o, hipStre
 
 bool gemm_ln_fusable(const GemmArgs& a) {
     return a.Wl == nullptr && a.N == 512 && a.K % 64 == 0 && a.M >= 1024 && a.lda % 8 == 0 && a.ldw % 8 == 0 && !a.relu && !a.scale &&
-           !a.res && !a.out32 && a.res16 && a.res8 && a.out16 && a.out8 && !a.a_tiled;
+           !a.res && !a.out32 && a.res16 && a.out16 && (a.res8 != nullptr) == (a.out8 != nullptr) && !a.a_tiled;
 }
 
 template <bool W2, bool CONV>

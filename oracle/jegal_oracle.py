@@ -120,14 +120,15 @@ def pad_clip(frames01, pad=12):
     return torch.cat([f[:1].expand(pad, -1, -1, -1), f, f[-1:].expand(pad, -1, -1, -1)], 0)
 
 
-def gestsync_clip_feats(sd, frames01, naive=False, batch_size=48, num_frames=25):
+def gestsync_clip_feats(sd, frames01, naive=False, batch_size=48, num_frames=25, return_conv=False):
     """Per-clip GestSync features (inference_embs.py:476-522 / extract_gestsync_feats.py:314-344):
     frames01 (T,H,W,3) fp32 in [0,1] -> edge-pad 12 -> T windows of 25, stride 1 ->
     forward_vid -> mean over the 21 output steps -> (T,1024).
 
     naive=True follows the reference literally (every window through the conv stack);
     naive=False runs the conv stack once over the padded clip and slices [i:i+21], which
-    is exactly equal (temporal kernels are (5,1,1,1,1,1), no temporal padding)."""
+    is exactly equal (temporal kernels are (5,1,1,1,1,1), no temporal padding).
+    return_conv (naive=False only): also return the conv stack's output (512, P-4) (tests: conditioning of what follows it)."""
     padded = pad_clip(frames01)                         # (P,H,W,3)
     P = padded.shape[0]
     n_win = P - num_frames + 1
@@ -149,6 +150,19 @@ def gestsync_clip_feats(sd, frames01, naive=False, batch_size=48, num_frames=25)
             e = min(n_win, s + batch_size)
             oc = torch.stack([conv[:, i:i + num_frames - 4] for i in range(s, e)])
             feats.append(gestsync_head(sd, oc).mean(-1))
+        if return_conv:
+            return torch.cat(feats, 0), conv
+    return torch.cat(feats, 0)
+
+
+def gestsync_feats_from_conv(sd, conv, batch_size=48, num_frames=25):
+    """The tail of gestsync_clip_feats(naive=False): conv (512, P-4) -> windows of 21 positions -> gestsync_head -> mean -> (T,1024)."""
+    n_win = conv.shape[1] - (num_frames - 4) + 1
+    feats = []
+    for s in range(0, n_win, batch_size):
+        e = min(n_win, s + batch_size)
+        oc = torch.stack([conv[:, i:i + num_frames - 4] for i in range(s, e)])
+        feats.append(gestsync_head(sd, oc).mean(-1))
     return torch.cat(feats, 0)
 
 

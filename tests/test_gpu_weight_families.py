@@ -7,11 +7,13 @@ span decades, and sharp attention (q / k projections x 2 and x 4).  Per family: 
 tri-modal content path at config-3 shapes (two clips) and 12 layers of XLM-RoBERTa, in every precision treatment a driver could
 select.  Every rel-L2 / max-abs is printed and collected in gpurun_out/family_table.json (DESIGN.md section 3 quotes it).
 
-Conditioning.  The x 4 family (attention logits x 16) is ill-conditioned as a NETWORK: in float64 a relative perturbation of 1e-6 of the
-JEGAL branch's input moves its output by ~2.4e-5 (the test measures this factor per family; the Gaussian draw: 0.4, x 2: 1.1).  An
-output tolerance of 1e-3 then asks for GestSync features good to 4e-5 -- an order below what ANY 16-bit operand format delivers
-(fp16: 2^-11 per operand, measured 4-5e-4 at the features), the reference's own CUDA autocast path included.  Families whose factor
-exceeds 2 are reported and held to factor x 1e-3 instead of 1e-3; the others must meet the contract in the mode the drivers select.
+Conditioning.  The x 4 family (attention logits x 16) is ill-conditioned as a NETWORK: the test measures, in float64, how much a
+relative perturbation (1e-6) of the conv stack's output moves the final embedding through GestSync's transformer + ff_vid + the JEGAL
+branch.  Gaussian draw: 0.10, heavy: 0.08, x 2: 0.28, x 4: 1.7 (T = 40 figures) -- the x 4 net amplifies every upstream rounding 17 times
+more than the net the 1e-3 contract was written for, in ANY implementation (with random features at the JEGAL branch's input that
+branch alone amplifies x 24: a 1e-4 input perturbation moves its fp64 output by 2.3e-3).  No 16-bit operand format (fp16: 2^-11 per
+operand; the reference's own CUDA autocast path is the same arithmetic) can hold 1e-3 there.  Rule: a family whose factor is within
+3 x the Gaussian draw's must meet 1e-3 in the mode the drivers select; beyond that it is REPORTED and held to 1e-3 x factor ratio / 3.
 """
 import json
 import os
@@ -50,15 +52,34 @@ def fam_id(f):
     return f"{f[0]}+{f[1]}"
 
 
-def amplification(jt, feats):
-    """Relative change of the fp64 JEGAL gesture embedding per relative input perturbation (1e-6, seeded Gaussian)."""
+def amplification(gt, jt, conv):
+    """Relative change of the fp64 gesture embedding per relative perturbation (1e-6, seeded Gaussian) of the conv stack's output
+    (512, P-4): GestSync transformer + ff_vid + mean + JEGAL gesture branch + normalisation."""
+    gd = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in gt.items()}
     jd = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in jt.items()}
-    x = torch.from_numpy(np.asarray(feats, np.float64))[None]
-    n = torch.from_numpy(np.random.default_rng(7).standard_normal(tuple(x.shape)))
+    c = conv.double()
+    n = torch.from_numpy(np.random.default_rng(7).standard_normal(tuple(c.shape)))
+
+    def f(v):
+        ft = O.gestsync_feats_from_conv(gd, v)
+        return O.l2_normalize(O.jegal_forward_inference(jd, visual_feats=ft[None], visual_mask=torch.ones(1, ft.shape[0], dtype=torch.float64))[0])
     with torch.no_grad():
-        f = lambda v: O.l2_normalize(O.jegal_forward_inference(jd, visual_feats=v, visual_mask=torch.ones(1, v.shape[1], dtype=torch.float64))[0])
-        a, b = f(x), f(x * (1 + 1e-6 * n))
+        a, b = f(c), f(c * (1 + 1e-6 * n))
     return float((b - a).norm() / a.norm()) / 1e-6
+
+
+_GAUSS_AMP = []
+_GAUSS_XLMR_AMP = []
+
+
+def gauss_amplification(frames0):
+    """The same factor for the reference family (the seeded Gaussian draw the 1e-3 contract was written on), once per session."""
+    if not _GAUSS_AMP:
+        gt, jt = O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+        with torch.no_grad():
+            _, conv = O.gestsync_clip_feats(gt, torch.from_numpy(frames0.astype(np.float32) / np.float32(255.0)), return_conv=True)
+        _GAUSS_AMP.append(amplification(gt, jt, conv))
+    return _GAUSS_AMP[0]
 
 
 def gesture_modes():
@@ -87,17 +108,20 @@ def test_gesture_and_content_across_weight_families(family):
     tbatch = [[w[0] for w in wb] for wb in wbs]
     pack = (torch.from_numpy(states), torch.from_numpy(tmask), tbatch, ids, offs)
     refs = []
+    conv0 = None
     with torch.no_grad():
         for b in range(B):
-            f = O.gestsync_clip_feats(gt, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+            f, conv = O.gestsync_clip_feats(gt, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)), return_conv=True)
+            conv0 = conv if conv0 is None else conv0
             g = O.l2_normalize(O.jegal_forward_inference(jt, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
             refs.append((f.numpy(), g.numpy()))
         cref = O.l2_normalize(O.jegal_forward_inference(jt, text=pack, audio=torch.from_numpy(mel), audio_mask=None, word_boundaries=wbs)).numpy()
     assert np.isfinite(cref).all() and all(np.isfinite(r[1]).all() for r in refs)
-    amp = amplification(jt, refs[0][0])
-    bound = TOL * max(1.0, amp / 2.0) if amp > 2.0 else TOL
-    print(f"\n[{fam_id(family)}] conditioning of the JEGAL branch (fp64, d out / d in): {amp:.2f} -> bound {bound:.2e}", end="")
-    record(f"{fam_id(family)}/conditioning", amplification=amp, bound=bound)
+    amp, amp_ref = amplification(gt, jt, conv0), gauss_amplification(frames[0])
+    ratio = amp / amp_ref
+    bound = TOL if ratio <= 3.0 else TOL * ratio / 3.0
+    print(f"\n[{fam_id(family)}] conditioning (fp64, d embedding / d conv features): {amp:.3f} = {ratio:.1f} x the Gaussian draw's -> bound {bound:.2e}", end="")
+    record(f"{fam_id(family)}/conditioning", amplification=amp, ratio_to_gauss=ratio, bound=bound)
     dev = torch.from_numpy(frames).cuda()
     worst = {}
     for mname, mode, cal in gesture_modes():
@@ -134,18 +158,25 @@ def test_xlmr_12_layers_across_weight_families(family):
     name, off = family
     sd = synth.xlmr_state_dict(seed=synth.XLMR_SEED + off, layers=12, family=name)
     ids, mask = synth.xlmr_inputs(55, 8, 48)
+    m = torch.from_numpy(mask).bool()
+
+    def xlmr_amp(w_sd, base=None):
+        """relative change of the output per relative perturbation (1e-4, fp32 oracle) of the word embeddings"""
+        sd2 = dict(w_sd)
+        w = w_sd["embeddings.word_embeddings.weight"]
+        sd2["embeddings.word_embeddings.weight"] = (w * (1 + 1e-4 * np.random.default_rng(7).standard_normal(w.shape))).astype(np.float32)
+        with torch.no_grad():
+            base = O.xlmr_forward(w_sd, ids, mask) if base is None else base
+            return rel(O.xlmr_forward(sd2, ids, mask)[m].numpy(), base[m].numpy()) / 1e-4
     with torch.no_grad():
         ref = O.xlmr_forward(sd, ids, mask)
-        # conditioning: relative change of the output per relative perturbation (1e-4, fp32 oracle) of the word embeddings
-        sd2 = dict(sd)
-        w = sd["embeddings.word_embeddings.weight"]
-        sd2["embeddings.word_embeddings.weight"] = (w * (1 + 1e-4 * np.random.default_rng(7).standard_normal(w.shape))).astype(np.float32)
-        ref2 = O.xlmr_forward(sd2, ids, mask)
-    m = torch.from_numpy(mask).bool()
-    amp = rel(ref2[m].numpy(), ref[m].numpy()) / 1e-4
-    bound = TOL * amp / 2.0 if amp > 2.0 else TOL
-    print(f"\n[{fam_id(family)}] xlmr conditioning (d out / d embeddings): {amp:.2f} -> bound {bound:.2e}", end="")
-    record(f"{fam_id(family)}/xlmr_conditioning", amplification=amp, bound=bound)
+    if not _GAUSS_XLMR_AMP:
+        _GAUSS_XLMR_AMP.append(xlmr_amp(synth.xlmr_state_dict(layers=12)))
+    amp = xlmr_amp(sd, ref)
+    ratio = amp / _GAUSS_XLMR_AMP[0]
+    bound = TOL if ratio <= 3.0 else TOL * ratio / 3.0
+    print(f"\n[{fam_id(family)}] xlmr conditioning (d out / d embeddings): {amp:.2f} = {ratio:.1f} x the Gaussian draw's -> bound {bound:.2e}", end="")
+    record(f"{fam_id(family)}/xlmr_conditioning", amplification=amp, ratio_to_gauss=ratio, bound=bound)
     ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
     errs = {}
     for mname in ("hi_lo", "bc_builtin_ids", "bc_own_ids"):
