@@ -73,7 +73,9 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "qkv0_linear"     1: the first transformer layer's qkv projection runs over the T+4 distinct conv positions and the 21
  *                     positional rows (linearity of W(conv + pe) + b); the attention kernel gathers and sums the rows
  *   "edge_dedup"      1: evaluate only the T+4 distinct padded-clip positions
- *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled fp16 + fp8 token stream)
+ *   "fuse_ln"         1: residual + LayerNorm fused into the GestSync projection GEMMs (tiled token stream)
+ *   "stream_fp16"     1: that token stream is the fp16 plane alone (post-norm: the LayerNorm output is rounded to fp16 as the next GEMM's
+ *                     operand anyway; -1.5 % per step); 0: fp16 + one e4m3 byte of correction per element (rounds 2-4)
  *   "attn_mfma"       1: MFMA attention kernels for S <= 160, dk = 64
  *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
  *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_options_scale_multirank.py flips every one of them)

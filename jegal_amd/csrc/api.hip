@@ -112,7 +112,7 @@ struct jg_handle {
     std::vector<Lin*> bc_layers;   // bias-corrected layers of both models (entries of a model are dropped on its re-finalize)
     int chunk = 32;                // clips per GestSync pass: ~14 GB of workspace per lane at 150 frames; 288 GB of HBM make the whole BASELINE batch one pass
     bool fuse_ln = true;           // residual + LayerNorm in the GEMM epilogue (GestSync post-norm layers)
-    bool stream8 = true;           // option "stream8": the fused transformer's token stream carries the 8-bit correction plane (0: fp16 plane alone)
+    bool stream8 = false;          // option "stream_fp16" = 0: the fused transformer's token stream carries an 8-bit correction plane next to the fp16 plane
     bool edge_dedup = true;        // skip the 16 duplicated edge positions of a padded clip
     bool conv1_direct = true;      // fused u8 conv1 kernel (false: stack_frames + implicit GEMM)
     f16* gs_qpe = nullptr;         // [21][1536]: layer-0 W_qkv pe[j] + b (Qkv0); recomputed when weights or bias corrections change
@@ -819,7 +819,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             e.out16 = qpos; e.no_bias = 1;
             RET(gemm(h, JG_ST_GEMM, q0->conv16, 512, q0->nclip * q0->P, L.qkv, e));
             if (!h->gs_qpe_valid) {
-                RET(timed(h, JG_ST_GEMM, [&] { return launch_pe_project(h->gs_pe, S, L.qkv.wh, L.qkv.wl, L.qkv.bias, 1536, 512, qpe, h->stream); }));
+                RET(timed(h, JG_ST_GEMM, [&] { return launch_pe_project(h->gs_pe, S, L.qkv.wh, L.qkv.rc ? L.qkv.wl_calib : L.qkv.wl, L.qkv.bias, 1536, 512, qpe, h->stream); }));
                 HIPCHK(h, hipStreamSynchronize(h->stream));      // once per weight load: later calls may come on another stream
                 h->gs_qpe_valid = true;
             }
@@ -1547,7 +1547,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     EngineOpts& o = h->opts;
     if (!std::strcmp(name, "conv1_direct")) { h->conv1_direct = value != 0; return JG_OK; }
     if (!std::strcmp(name, "fuse_ln")) { h->fuse_ln = value != 0; return JG_OK; }
-    if (!std::strcmp(name, "stream8")) { h->stream8 = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "stream_fp16")) { h->stream8 = value == 0; return JG_OK; }
     if (!std::strcmp(name, "edge_dedup")) { h->edge_dedup = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_mfma16")) { o.conv1_mfma16 = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }

@@ -707,18 +707,18 @@ hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, 
 // (rows r = 0 .. rpc-1 relative to the clip's first row; sample: every row when rpc < 1024, otherwise the 16-row runs
 // (r >> 4) % 8 == 0 -- the error of a sampled mean is the row spread / sqrt(rows sampled), a few per cent of what the correction
 // removes).  Two launches: column means per clip (one workgroup per clip and 128-column slab, fixed summation order), then the skinny
-// product (one wave -- or, at K = 2048, one workgroup -- per output column).  Deterministic.
+// product on the matrix cores.  Deterministic.
 __device__ __forceinline__ int rc_rows_sampled(int rpc) {
     if (rpc < 1024) return rpc;
     int cnt = 0;
     for (int r0 = 0; r0 < rpc; r0 += 128) cnt += rpc - r0 < 16 ? rpc - r0 : 16;
     return cnt;
 }
-__global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc, int K, float* __restrict__ mean) {
-    __shared__ float red[16][16 * 8 + 1];
+__global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc, int K, f16* __restrict__ mean) {
+    __shared__ float red[32][8 * 8 + 1];
     const int clip = blockIdx.x, t = threadIdx.x;
-    const int cg = t & 15, rl = t >> 4;                         // 16 column groups of 8 (a 128-column slab) x 16 row lanes
-    const int n = blockIdx.y * 128 + cg * 8;
+    const int cg = t & 7, rl = t >> 3;                          // 8 column groups of 8 (a 64-column slab) x 32 row lanes
+    const int n = blockIdx.y * 64 + cg * 8;
     const int step = rpc < 1024 ? 16 : 128;                     // 16-row runs: every one, or every eighth
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto row_ptr = [&](int r) -> const f16* {
@@ -726,16 +726,17 @@ __global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict_
         return tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
                      : A + m * lda + n;
     };
-    // row lane rl takes row rl of every sampled run; four loads in flight per thread (the loop is a latency chain otherwise), summed
-    // in row order whatever the grouping
-    int r = rl;
-    for (; r + 3 * step < rpc; r += 4 * step) {
-        const f16x8 v0 = *reinterpret_cast<const f16x8*>(row_ptr(r)), v1 = *reinterpret_cast<const f16x8*>(row_ptr(r + step));
-        const f16x8 v2 = *reinterpret_cast<const f16x8*>(row_ptr(r + 2 * step)), v3 = *reinterpret_cast<const f16x8*>(row_ptr(r + 3 * step));
+    // row lane rl takes row (rl & 15) of every second sampled run (runs of its parity rl >> 4); four loads in flight per thread (the
+    // loop is a latency chain otherwise), summed in a fixed order
+    const int stride = 2 * step;
+    int r = (rl & 15) + (rl >> 4) * step;
+    for (; r + 3 * stride < rpc; r += 4 * stride) {
+        const f16x8 v0 = *reinterpret_cast<const f16x8*>(row_ptr(r)), v1 = *reinterpret_cast<const f16x8*>(row_ptr(r + stride));
+        const f16x8 v2 = *reinterpret_cast<const f16x8*>(row_ptr(r + 2 * stride)), v3 = *reinterpret_cast<const f16x8*>(row_ptr(r + 3 * stride));
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = (((acc[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
     }
-    for (; r < rpc; r += step) {
+    for (; r < rpc; r += stride) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(row_ptr(r));
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
@@ -743,45 +744,45 @@ __global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
     __syncthreads();
-    if (t < 128) {
+    if (t < 64) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s += red[q][t];
-        mean[(long)clip * K + blockIdx.y * 128 + t] = s / (float)rc_rows_sampled(rpc);
+        for (int q = 0; q < 32; ++q) s += red[q][t];
+        mean[(long)clip * K + blockIdx.y * 64 + t] = (f16)(s / (float)rc_rows_sampled(rpc));
     }
 }
-// out[c][n] = bias[n] + sum_k lo[n][k] * mean[c][k].  K / 8 threads share one output column (64 = one wave at K = 512, the whole
-// workgroup at K = 2048); each holds its 8 weights and walks the clips.
-__global__ __launch_bounds__(256) void rc_gemv_kernel(const float* __restrict__ mean, const f16* __restrict__ lo, const float* __restrict__ bias,
+// out[c][n] = bias[n] + sum_k lo[n][k] * mean[c][k]: a 32-clip x 32-column tile per workgroup on v_mfma_f32_32x32x16 (A = the lo rows,
+// B = the clip means as fp16 -- the mean's own rounding, 2^-12, scales a term that is 3e-4 of the output), the four waves split K and
+// meet in LDS.  (The VALU form of this product -- a wave-wide reduction per clip and column -- took 17 us per Linear, twice the
+// column means; rocprofv3, round 5.)
+__global__ __launch_bounds__(256) void rc_gemv_kernel(const f16* __restrict__ mean16, const f16* __restrict__ lo, const float* __restrict__ bias,
                                                       int nclips, int N, int K, float* __restrict__ out) {
-    __shared__ float red[4][32];
+    __shared__ float red[3][16][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int tpn = K >> 3;                                     // threads per output column
-    const int npb = 256 / tpn;                                  // columns per workgroup: 4 or 1
-    const int n = blockIdx.x * npb + (npb == 4 ? wave : 0);
-    const int k0 = (npb == 4 ? lane : t) * 8;
-    const f16x8 wv = *reinterpret_cast<const f16x8*>(lo + (long)n * K + k0);
-    float w[8];
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int cl = c0 + r31 < nclips ? c0 + r31 : nclips - 1;
+    const int kq = K >> 2;                                       // this wave's share of K
+    const f16* ap = lo + (long)(n0 + r31) * K + wave * kq + 8 * hh;
+    const f16* bp = mean16 + (long)cl * K + wave * kq + 8 * hh;
+    f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) w[e] = (float)wv[e];
-    for (int c0 = 0; c0 < nclips; c0 += 32) {
-        const int nc = nclips - c0 < 32 ? nclips - c0 : 32;
-        float mine = 0.f;                                       // lane c (< nc) ends up with clip c0 + c's sum over this wave's k
-        for (int c = 0; c < nc; ++c) {
-            const float* p = mean + (long)(c0 + c) * K + k0;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-            float v = w[0] * a.x + w[1] * a.y + w[2] * a.z + w[3] * a.w + w[4] * b.x + w[5] * b.y + w[6] * b.z + w[7] * b.w;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k = 0; k < kq; k += 16) {
+        const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k), b = *reinterpret_cast<const f16x8*>(bp + k);
+        acc = JG_MFMA_32x32x16(a, b, acc);
+    }
+    if (wave) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == c) mine = v;
-        }
-        if (npb == 4) {
-            if (lane < nc) out[(long)(c0 + lane) * N + n] = (bias ? bias[n] : 0.f) + mine;
-        } else {
-            __syncthreads();
-            if (lane < 32) red[wave][lane] = mine;
-            __syncthreads();
-            if (t < nc) out[(long)(c0 + t) * N + n] = (bias ? bias[n] : 0.f) + ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+        for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0 && c0 + r31 < nclips) {
+        // register i <-> column n0 + (i & 3) + 8 (i >> 2) + 4 hh, lane <-> clip
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            out[(long)(c0 + r31) * N + n] = (bias ? bias[n] : 0.f) + (((acc[i] + red[0][i][lane]) + red[1][i][lane]) + red[2][i][lane]);
         }
     }
 }
@@ -791,9 +792,10 @@ size_t rc_scratch_elems(int nclips, int K) { return (size_t)nclips * K; }
 hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const f16* lo, const float* bias, int N, int K, float* scratch,
                           float* out, hipStream_t s) {
     if (nclips <= 0 || rpc <= 0) return hipSuccess;
-    if ((K != 512 && K != 2048) || (tiled && K != 512) || (N & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rc_col_mean_kernel, dim3(nclips, K / 128), dim3(256), 0, s, A, lda, tiled, rpc, K, scratch);
-    hipLaunchKernelGGL(rc_gemv_kernel, dim3(K == 512 ? N / 4 : N), dim3(256), 0, s, scratch, lo, bias, nclips, N, K, out);
+    if ((K != 512 && K != 2048) || (tiled && K != 512) || (N & 31)) return hipErrorInvalidValue;
+    f16* mean16 = reinterpret_cast<f16*>(scratch);
+    hipLaunchKernelGGL(rc_col_mean_kernel, dim3(nclips, K / 64), dim3(256), 0, s, A, lda, tiled, rpc, K, mean16);
+    hipLaunchKernelGGL(rc_gemv_kernel, dim3(N / 32, (nclips + 31) / 32), dim3(256), 0, s, mean16, lo, bias, nclips, N, K, out);
     return hipGetLastError();
 }
 

@@ -470,7 +470,7 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         // read-once stream: nontemporal, so it does not push the weights out of L2
         const u32x2 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp)), r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 256));
         const u32x2 r2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 512)), r3 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(xp + 768));
-        // res8 == nullptr (option stream8 = 0, round 5): the token stream is the fp16 plane alone -- in a post-norm transformer the
+        // res8 == nullptr (option stream_fp16 = 1, the default since round 5): the token stream is the fp16 plane alone -- in a post-norm transformer the
         // LayerNorm output is rounded to fp16 as the next GEMM's operand anyway, and carrying the residual at that precision costs
         // 1-5 % of the feature error (oracle/precision_families.py) for a third fewer stream bytes and no codec arithmetic
         u32x4 dq = {0u, 0u, 0u, 0u};

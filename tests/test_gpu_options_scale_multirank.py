@@ -89,7 +89,7 @@ def test_jegal_text_long_sequences(models, oracle_sd, L):
 
 # ------------------------------------------------------------------ (b) every A/B switch and W2_ALL
 OPTIONS = ["attn_mfma", "fuse_ln", "gemm_glds", "gemm_persistent", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile",
-           "gemm_counted", "conv1_zero_skip", "conv2_row_skip", "qkv0_linear", "conv1_direct", "edge_dedup", "dual_stream", "conv1_mfma16"]
+           "gemm_counted", "conv1_zero_skip", "conv2_row_skip", "qkv0_linear", "conv1_direct", "edge_dedup", "dual_stream", "conv1_mfma16", "stream_fp16"]
 
 
 @pytest.fixture(scope="module")

@@ -1,5 +1,5 @@
 """A/B an engine option on ONE box, alternating runs of bench.py (boxes differ by +-3 %, so only same-call pairs are credible).
-  python tools/ab_option.py <name> <valueA> <valueB> [pairs=3] [bench.py options ...]     e.g.  ab_option.py stream8 1 0 3 --precision 5"""
+  python tools/ab_option.py <name> <valueA> <valueB> [pairs=3] [bench.py options ...]     e.g.  ab_option.py stream_fp16 0 1 3 --precision 5"""
 import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
