@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=3, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16")
+    ap.add_argument("--precision", type=int, default=5, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (default), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
@@ -538,7 +538,7 @@ def main():
         # engine per mode (the precision is fixed at finalize), same inputs, same number of steps, stage table from bracketed steps.
         if world == 1:
             extras["precision_modes"] = {}
-            for mode, name in ((5, "rc"), (1, "w2")):
+            for mode, name in ((5, "rc"), (3, "bc"), (1, "w2")):
                 if mode == args.precision:
                     continue
                 e2 = Engine(local_dev, precision=mode)
@@ -654,10 +654,11 @@ def main():
                 res["config3"] = extras["config3"]
             if extras.get("precision_modes"):
                 res["precision_modes"] = dict(extras["precision_modes"],
-                                              what="the SAME timed loop (same clips, steps, two lanes) in the calibration-free precision treatments: rc = "
-                                                   "JG_PREC_FP16_RC (per-clip run-time correction; what the CLI drivers select for a checkpoint they have "
-                                                   "never seen), w2 = JG_PREC_FP16_W2 (hi+lo Linear weights); `value` above is the default mode "
-                                                   "(JG_PREC_FP16_BC, corrections from a calibration pass)")
+                                              what="the SAME timed loop (same clips, steps, two lanes) in the other precision treatments: `value` above is "
+                                                   "JG_PREC_FP16_RC (per-clip run-time correction, calibration-free: what the CLI drivers select for a "
+                                                   "checkpoint they have never seen); bc = JG_PREC_FP16_BC (corrections folded into the biases by a "
+                                                   "calibration pass: the library's default for the seeded weights, or with caller-supplied calibration clips), "
+                                                   "w2 = JG_PREC_FP16_W2 (hi+lo Linear weights, calibration-free)")
             if "pcie_clips_per_s" in extras:
                 res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",
                                          "what": "host-resident clips -> pinned buffers -> H2D under compute -> embeddings back on the host (GestureStreamer); never `value`"}

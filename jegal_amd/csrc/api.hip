@@ -1663,7 +1663,7 @@ int jg_calibrate_gesture(jg_handle* h, const void* frames, int dtype, int B, int
 
 int jg_calibrate_xlmr(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L) {
     ENTER(h);
-    if (h->precision != JG_PREC_FP16_BC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC");
+    if (h->precision != JG_PREC_FP16_BC && h->precision != JG_PREC_FP16_RC) JG_FAIL(h, JG_ERR_STATE, "calibration only applies to JG_PREC_FP16_BC / JG_PREC_FP16_RC");
     if (input_ids && (B <= 0 || L <= 0)) JG_FAIL(h, JG_ERR_ARG, "bad calibration batch");
     return calibrate_xlmr(h, input_ids, attention_mask, B, L);
 }
@@ -1739,7 +1739,8 @@ int jg_debug_gemm_ex(jg_handle* h, const void* a16, const void* w16, int M, int 
     if (mode & 2) { a.res = x32; a.ldr = N; a.out32 = x32; } else { a.out16 = o16; }
     if (mode & 8) {      // residual + LayerNorm fused (N = 512): gamma/beta = the zero bias vector, timing only
         a.res = nullptr; a.out32 = nullptr;
-        a.res16 = o16; a.res8 = reinterpret_cast<signed char*>(x32); a.out16 = o16; a.out8 = reinterpret_cast<signed char*>(x32);
+        a.res16 = o16; a.out16 = o16;
+        if (h->stream8) { a.res8 = reinterpret_cast<signed char*>(x32); a.out8 = reinterpret_cast<signed char*>(x32); }      // (option stream_fp16 = 0)
         a.ln_w = bias; a.ln_b = bias; a.ln_flavour = LN_STD;
     }
     if (mode & 48) {     // implicit LayerNorm, timing only: 16 = consumer (ln_mode 1), 32 = producer (ln_mode 2); statistics / planes = the scratch buffers

@@ -40,23 +40,24 @@ def load_checkpoint(path, kind):
 
 
 def _add_precision_args(p):
-    p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3],
+    p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3, 5],
                    help="engine precision mode (include/jegal_hip.h); default: 3 (bias-corrected fp16) for the seeded synthetic "
-                        "weights or when --calibrate_frames is given, 1 (hi+lo fp16 Linear weights, calibration-free) for real checkpoints")
+                        "weights or when --calibrate_frames is given, 5 (run-time corrected fp16: per-clip, calibration-free) for real checkpoints")
     p.add_argument("--calibrate_frames", default=None,
                    help=".npy of masked uint8 crops (B,T,270,480,3) or (T,270,480,3): re-run the precision-mode-3 calibration on them")
 
 
 #: engine precision mode (include/jegal_hip.h) a driver selects for a checkpoint it has never seen, unless calibration clips are
 #: supplied: calibration-free by construction.  tests/test_gpu_weight_families.py holds THIS mode to 1e-3 on every weight family.
-REAL_CHECKPOINT_PRECISION = 1          # PREC_FP16_W2 (PREC_FP16_RC = 5 once measured)
+REAL_CHECKPOINT_PRECISION = 5          # PREC_FP16_RC: per-clip run-time correction (round 5; rounds 3-4: 1 = PREC_FP16_W2, 1.4x slower)
 
 
 def pick_precision(args, checkpoints, can_calibrate=True):
-    """The default precision mode folds (w - fp16(w)).E[x] into every Linear bias, with E[x] recorded on built-in synthetic clips.
-    That calibration was only ever validated on the synthetic weights (no checkpoints ship with the reference), so a REAL
-    checkpoint gets the calibration-free hi+lo mode unless the caller supplies calibration clips AND
-    the command can run the calibration on them (can_calibrate: it needs the GestSync model, frames -> features -> JEGAL)."""
+    """The library's default precision mode folds (w - fp16(w)).E[x] into every Linear bias, with E[x] recorded on built-in synthetic
+    clips.  That calibration was only ever validated on the synthetic weights (no checkpoints ship with the reference), so a REAL
+    checkpoint gets the calibration-free run-time corrected mode (E[x] per clip from the clip's own rows, JG_PREC_FP16_RC; held to
+    1e-3 on every weight family by tests/test_gpu_weight_families.py) unless the caller supplies calibration clips (INTEGRATION.md
+    section 6) AND the command can run the calibration on them (can_calibrate: it needs the GestSync model, frames -> features -> JEGAL)."""
     from ._lib import PREC_FP16_BC
     if getattr(args, "precision", None) is not None:
         return args.precision

@@ -1,0 +1,109 @@
+"""JG_PREC_FP16_RC (round 5): single-fp16 Linear weights on the GestSync transformer with the systematic part of
+the weight-rounding error, (w - fp16(w)) . E[x], rebuilt per GEMM call and PER CLIP from a fixed sample of the clip's own rows --
+no calibration pass, nothing depends on calibration data or on the rest of the batch.  Through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import jegal_oracle as O
+from jegal_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def rel(a, b):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def rc():
+    from jegal_amd._lib import Engine, PREC_FP16_RC
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    e = Engine(0, precision=PREC_FP16_RC)
+    GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+    yield e
+    e.close()
+
+
+def test_rc_full_length_clips_vs_oracle(rc):
+    gsd, jsd = O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+    T = 150
+    frames = synth.synth_frames(4321, 3, T)
+    emb = rc.extract_gesture(torch.from_numpy(frames).cuda()).cpu().numpy()
+    feats = rc.gestsync_clip(torch.from_numpy(frames).cuda()).cpu().numpy()
+    for b in (0, 2):
+        with torch.no_grad():
+            f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+            g = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy()
+        r, mx, rf = rel(emb[b], g), float(np.abs(emb[b] - g).max()), rel(feats[b], f.numpy())
+        print(f"\nRC clip {b}: embedding rel-L2 {r:.3e} max-abs {mx:.3e} | GestSync feats {rf:.3e}", end="")
+        assert r < TOL and mx < TOL and rf < TOL
+
+
+def test_rc_result_of_a_clip_does_not_depend_on_the_batch(rc):
+    """The correction of a clip comes from ITS rows (sampled relative to the clip's first row): the same clip alone, first, last or in
+    the middle of a batch, in either lane of a two-lane batch, gives the same bits (every GEMM instance accumulates k in the same
+    order, tests/test_gpu_precision_uploads.py::test_gemm_tile_choice_never_changes_a_bit)."""
+    T = 60
+    clips = synth.synth_frames(777, 9, T)
+    dev = torch.from_numpy(clips).cuda()
+    alone_f = rc.gestsync_clip(dev[4:5]).clone()
+    alone_e = rc.extract_gesture(dev[4:5]).clone()
+    for lo, hi in ((4, 6), (2, 5), (0, 9), (3, 5)):
+        assert torch.equal(rc.gestsync_clip(dev[lo:hi])[4 - lo], alone_f[0]), (lo, hi)
+        # (the JEGAL branch of a 60-frame clip ALONE takes the register-staged GEMM, M < 128, whose fp32 summation order differs)
+        assert rel(rc.extract_gesture(dev[lo:hi])[4 - lo], alone_e[0]) < 1e-5, (lo, hi)
+    # two different neighbours: nothing leaks from them
+    other = torch.from_numpy(synth.synth_frames_structured(5, 2, T, "saturated")).cuda()
+    mixed = rc.gestsync_clip(torch.cat([other[:1], dev[4:5], other[1:]]))
+    assert torch.equal(mixed[1], alone_f[0])
+    rc.set_option("dual_stream", 0)
+    try:
+        assert torch.equal(rc.gestsync_clip(dev)[4], alone_f[0])
+    finally:
+        rc.set_option("dual_stream", 1)
+
+
+@pytest.mark.parametrize("opt", ["fuse_ln", "gemm_glds", "qkv0_linear", "stream_fp16", "gemm_big_tile", "dual_stream"])
+def test_rc_options_fall_back_to_hi_lo_or_stay_within_tolerance(rc, opt):
+    """Where the per-clip epilogue is not available (unfused LayerNorm, register-staged GEMM) the run-time corrected layers run hi+lo:
+    never single fp16 without its correction."""
+    gsd, jsd = O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+    T = 60
+    frames = synth.synth_frames(5150, 2, T)
+    with torch.no_grad():
+        f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[0].astype(np.float32) / np.float32(255.0)))
+        g = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
+    dev = torch.from_numpy(frames).cuda()
+    base = rc.extract_gesture(dev).cpu()
+    rc.set_option(opt, 0)
+    try:
+        alt = rc.extract_gesture(dev).cpu()
+    finally:
+        rc.set_option(opt, 1)
+    print(f"\nRC {opt}=0: rel {rel(alt[0], g):.3e} (default {rel(base[0], g):.3e})", end="")
+    assert rel(base[0], g) < TOL and rel(alt[0], g) < TOL
+    assert torch.equal(rc.extract_gesture(dev).cpu(), base)
+
+
+def test_rc_short_and_windowed_inputs(rc):
+    """Clips too short for the fused plan (M < 1024 tokens) and the forward_vid drop-in (windows have no clip structure) run hi+lo."""
+    from jegal_amd.gestsync import GestSync
+    gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
+    frames = synth.synth_frames(31, 1, 5)
+    feats = rc.gestsync_clip(torch.from_numpy(frames).cuda()).cpu()
+    with torch.no_grad():
+        ref = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[0].astype(np.float32) / np.float32(255.0)))
+    assert rel(feats[0], ref) < TOL
+    x = torch.rand(2, 3, 25, 270, 480)
+    out = GestSync(engine=rc).load_state_dict(synth.gestsync_state_dict(include_unused=False)).forward_vid(x.cuda()).cpu()
+    with torch.no_grad():
+        refw = O.gestsync_forward_vid(gsd, x)
+    assert rel(out, refw) < TOL
+    with pytest.raises(Exception):
+        rc.calibrate()                                   # there is nothing to calibrate in this mode

@@ -209,15 +209,18 @@ def test_bench_launcher_fails_fast_when_a_rank_dies():
 
 def test_cli_drivers_pick_the_calibration_free_mode_for_real_checkpoints():
     """the default bias-corrected mode depends on a calibration that was validated on the synthetic weights
-    only; a real checkpoint runs hi+lo (mode 1) unless calibration clips or an explicit --precision are given."""
+    only; a real checkpoint runs a calibration-free mode -- since round 5 the run-time corrected one (mode 5: per-clip E[x]),
+    before that hi+lo (mode 1) -- unless calibration clips or an explicit --precision are given."""
     from types import SimpleNamespace as NS
-    from jegal_amd.drivers import pick_precision
+    from jegal_amd.drivers import pick_precision, REAL_CHECKPOINT_PRECISION
+    from jegal_amd._lib import PREC_FP16_RC
+    assert REAL_CHECKPOINT_PRECISION == PREC_FP16_RC == 5
     assert pick_precision(NS(precision=None, calibrate_frames=None), ["synthetic", None]) == 3
-    assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 1
+    assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 5
     assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/gestsync.pth"]) == 3
     assert pick_precision(NS(precision=0, calibrate_frames=None), ["/ckpt/jegal.pth"]) == 0
     # calibration clips only count when the command can run the calibration (needs GestSync: extract_jegal_embs cannot)
-    assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/jegal.pth"], can_calibrate=False) == 1
+    assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/jegal.pth"], can_calibrate=False) == 5
 
 
 def test_masked_packer_layout():
