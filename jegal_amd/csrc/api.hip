@@ -586,7 +586,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
             float *scr, *bc;
             RET(wsalloc(h, rc_scratch_elems(e.rc_clips, L.K), &scr));
             RET(wsalloc(h, (size_t)e.rc_clips * L.N, &bc));
-            RET(timed(h, JG_ST_MISC, [&] { return launch_rc_bias(A, lda, e.a_tiled, e.rc_clips, e.rc_rpc, L.wl_calib, L.bias, L.N, L.K, scr, bc, h->stream); }));
+            RET(timed(h, JG_ST_GEMM, [&] { return launch_rc_bias(A, lda, e.a_tiled, e.rc_clips, e.rc_rpc, L.wl_calib, L.bias, L.N, L.K, scr, bc, h->stream); }));
             a.bias_clip = bc; a.rpc = e.rc_rpc; a.nclips = e.rc_clips;
         } else {
             a.Wl = L.wl_calib;

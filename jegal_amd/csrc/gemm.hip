@@ -536,8 +536,30 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
                 for (int i = 0; i < 4; ++i) acc[i][j] = res_dec4(xw[i][0], xw[i][1], dw[i]);
             }
         }
+        // LNF: this tile's bias row(s) / gamma / beta -- one element per thread (BN == 512 threads), loaded under the LAST k-tile's MFMAs
+        // and parked in LDS right behind the loop (round 5: the loads used to sit between the loop and the first statistics barrier,
+        // ~1 us of L2 latency per tile).  Per-clip bias (GemmArgs::bias_clip): a 128-row tile meets at most two clips when rpc >= 128
+        // (launch_gemm checks); rows from csplit on take the second clip's vector.
+        float pf_b0 = 0.f, pf_b1 = 0.f, pf_g = 0.f, pf_be = 0.f;
+        int csplit = 0x7fffffff;
         for (int kt = 0; kt < nk; ++kt) {
             const bool pre = kt + 1 < nk;
+            if constexpr (LNF) {
+                if (kt == nk - 1) {
+                    const float* b0 = a.bias;
+                    const float* b1 = a.bias;
+                    if (a.bias_clip) {
+                        const int c0 = cm0 / a.rpc;
+                        b0 = a.bias_clip + (long)(c0 < a.nclips ? c0 : a.nclips - 1) * BN;
+                        b1 = a.bias_clip + (long)(c0 + 1 < a.nclips ? c0 + 1 : a.nclips - 1) * BN;
+                        csplit = (c0 + 1) * a.rpc;
+                    }
+                    pf_b0 = b0 ? b0[t] : 0.f;
+                    pf_b1 = b1 ? b1[t] : 0.f;
+                    pf_g = a.ln_w[t];
+                    pf_be = a.ln_b[t];
+                }
+            }
             if (pre) stage_begin(kt + 1);
             if (pre && !SPREAD) {
 #pragma unroll
@@ -652,23 +674,11 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
             constexpr int JD = 2;                                         // row block in front of which the next tile's DMA goes
             float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
             float* lnp = red + 2 * 8 * BM;                                // [4][BN]: bias, gamma, beta, bias of the tile's second clip
-            // per-clip bias (GemmArgs::bias_clip): a 128-row tile meets at most two clips when rpc >= 128 (launch_gemm checks); rows from
-            // csplit on take the second clip's vector
-            const float* b0 = a.bias;
-            const float* b1 = a.bias;
-            int csplit = 0x7fffffff;
-            if (a.bias_clip) {
-                const int c0 = cm0 / a.rpc;
-                b0 = a.bias_clip + (long)(c0 < a.nclips ? c0 : a.nclips - 1) * BN;
-                b1 = a.bias_clip + (long)(c0 + 1 < a.nclips ? c0 + 1 : a.nclips - 1) * BN;
-                csplit = (c0 + 1) * a.rpc;
-            }
-            for (int c = t; c < BN; c += 512) {
-                lnp[c] = b0 ? b0[c] : 0.f;
-                lnp[BN + c] = a.ln_w[c];
-                lnp[2 * BN + c] = a.ln_b[c];
-                lnp[3 * BN + c] = b1 ? b1[c] : 0.f;
-            }
+            static_assert(BN == 512, "one parked element per thread");
+            lnp[t] = pf_b0;
+            lnp[BN + t] = pf_g;
+            lnp[2 * BN + t] = pf_be;
+            lnp[3 * BN + t] = pf_b1;
             __syncthreads();
             const int ncol = wn * 64 + fq * 4;                            // + i*16: this lane's 4 columns of block i
             float rsum[MI];
