@@ -768,9 +768,15 @@ __global__ __launch_bounds__(256) void rc_gemv_kernel(const f16* __restrict__ me
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int k = 0; k < kq; k += 16) {
-        const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k), b = *reinterpret_cast<const f16x8*>(bp + k);
-        acc = JG_MFMA_32x32x16(a, b, acc);
+    for (int k = 0; k < kq; k += 128) {           // kq is 128 or 512: eight k-steps' operands in flight at a time
+        f16x8 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f16x8*>(ap + k + 16 * u);
+            b[u] = *reinterpret_cast<const f16x8*>(bp + k + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = JG_MFMA_32x32x16(a[u], b[u], acc);
     }
     if (wave) {
 #pragma unroll
