@@ -107,3 +107,24 @@ def test_rc_short_and_windowed_inputs(rc):
     assert rel(out, refw) < TOL
     with pytest.raises(Exception):
         rc.calibrate()                                   # there is nothing to calibrate in this mode
+
+
+@pytest.mark.parametrize("B,T,chunk", [(5, 13, 32), (40, 25, 64), (3, 37, 32), (2, 24, 32)])
+def test_rc_odd_shapes_vs_oracle(rc, B, T, chunk):
+    """Rows per clip below the sampling threshold (every row is used), not a multiple of 16 or of the tile height, more than 32 clips in
+    one pass (two clip groups in the correction product), and a batch too small for the fused plan (M < 1024: hi+lo)."""
+    gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
+    frames = synth.synth_frames(900 + T, B, T)
+    rc.set_chunk(chunk)
+    try:
+        feats = rc.gestsync_clip(torch.from_numpy(frames).cuda()).cpu()
+    finally:
+        rc.set_chunk(32)
+    assert torch.isfinite(feats).all()
+    worst = 0.0
+    for b in sorted({0, B // 2, B - 1}):
+        with torch.no_grad():
+            ref = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+        worst = max(worst, rel(feats[b], ref))
+    print(f"\nRC B={B} T={T} chunk={chunk}: GestSync feats rel-L2 (worst of 3 clips) {worst:.3e}", end="")
+    assert worst < TOL
