@@ -551,7 +551,9 @@ def main():
                     cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                     d2 = json.loads(cp.stdout.strip().splitlines()[-1])
                     extras["precision_modes"][name] = {"precision_mode": mode, "value": d2["value"], "ms_per_step": d2["ms_per_step"],
-                                                       "stage_ms_per_step": d2["stage_ms_per_step"]}
+                                                       "stage_ms_per_step": d2["stage_ms_per_step"],
+                                                       "roofline_linear_gemms_frac": d2["roofline_linear_gemms"]["frac"],
+                                                       "roofline_conv1_frac": d2["roofline"]["frac"]}
                 except Exception as exc:          # the headline must not depend on a secondary measurement
                     extras["precision_modes"][name] = {"precision_mode": mode, "error": repr(exc)[:200]}
     jdist.barrier()

@@ -233,9 +233,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //      instantiations, so that the epilogue code and its registers never reach the instances of the gesture path.
 //      XE = 1: consumer (ln_mode 1), XE = 2: producer (ln_mode 2); each is compiled with that one epilogue only (no residual, no
 //      tiled operand, no generic path: launch_gemm checks the shapes), which is what keeps the 256x256 instance free of spills.
-template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false, int XE = 0>
+// C32: conv instance for C == 32 input channels (JEGAL's second audio conv, cnn.3: 32 -> 64 channels, jegal.py:45-47): a 64-wide k-tile
+//      is then TWO taps x 32 channels, so a lane's tap depends on which half of the 128-B row its 16-B chunk sits in (one select per
+//      piece); with WN = 1 (N = 64) every wave stages ONE weight piece.
+template <bool W2, bool CONV, int MI, int WM, int WN, bool LNF = false, bool SPR = false, int XE = 0, bool C32 = false>
 __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles, int total_tiles, const f16* zeros, int counted_ok, unsigned long long* tl) {
     static_assert(WM * WN == 8, "8 waves");
+    static_assert(!C32 || (CONV && !SPR && !W2), "C32: plain conv instance, single fp16 weights");
     static_assert(!LNF || (WM == 1 && !W2), "fused LayerNorm needs a row-wide tile: all 8 waves side by side along n");
     static_assert(!XE || (!CONV && !LNF), "implicit-LayerNorm epilogues: plain GEMM instances only");
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
     const f16* xalt[ROWCONST ? XI : 1];          // the same pixel in the const image of the input (ROWCONST)
     int xpix[XI];
     int tidx = 0, tc0 = 0;
-    static_assert(WI % 2 == 0, "weight pieces come in even/odd pairs");
+    static_assert(WI % 2 == 0 || WI == 1, "weight pieces come in even/odd pairs (or one piece per wave: N = 64)");
     const f16* whb[2];
     const f16* wlb[2];
     int wchunk[2];
@@ -340,8 +344,9 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(GemmArgs a, int n_tiles,
                 ow += ow < 0 ? a.g.OW : (ow >= a.g.OW ? -a.g.OW : 0);
                 const int ih = oh * a.g.SH - a.g.PH, iw = ow * a.g.SW - a.g.PW;
                 const int rin = rowconst ? conv_skip_decode(s2, a.g.in_op) : 0;
-                xpix[i] = (ih << 20) | ((iw & 0xfff) << 8) | rin;      // |ih|, |iw| < 2048 (checked by launch_gemm), rin <= 19
-                xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
+                // C32: the low bit says which of the k-tile's two taps this lane's chunk belongs to (chunks 4-7 = the second tap)
+                xpix[i] = (ih << 20) | ((iw & 0xfff) << 8) | (C32 ? (c >> 2) : rin);      // |ih|, |iw| < 2048 (checked by launch_gemm), rin <= 19
+                xsrc[i] = a.A + (long)img * a.g.H * a.g.W * a.g.C + ((long)ih * a.g.W + iw) * a.g.C + (C32 ? (c & 3) * 8 : c * 8);
                 if constexpr (ROWCONST) xalt[i] = a.g.const_in + ((long)ih * a.g.W + iw) * a.g.C + c * 8;
             } else {
                 xpix[i] = 0;
@@ -370,9 +375,19 @@ xsrc[i] = (!XE && a.a_tiled) ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) *
     long stapoff = 0;
     int stkh = 0, stkw = 0;
     bool skin = true;
+    long stapoff2 = 0;           // C32: the k-tile's second tap
+    int stkh2 = 0, stkw2 = 0;
+    bool skin2 = false;
     auto stage_begin = [&](int kt) __attribute__((always_inline)) {
         sk0 = kt * 64;
-        if (CONV) {
+        if constexpr (C32) {
+            tap_decode(a.g, 2 * kt, stkh, stkw);
+            tap_decode(a.g, 2 * kt + 1, stkh2, stkw2);
+            stapoff = ((long)stkh * a.g.W + stkw) * a.g.C;
+            stapoff2 = ((long)stkh2 * a.g.W + stkw2) * a.g.C;
+            skin = sk0 < a.K;
+            skin2 = sk0 + 32 < a.K;
+        } else if (CONV) {
             if (kt == 0) tidx = tc0 = 0;
             tap_decode(a.g, tidx, stkh, stkw);
             stapoff = ((long)stkh * a.g.W + stkw) * a.g.C + tc0;
@@ -389,7 +404,12 @@ xsrc[i] = (!XE && a.a_tiled) ? a.A + (long)(m >> 7) * 65536 + ((m & 127) >> 4) *
         if (p < XI) {
             const int i = p;
             const f16* src;
-            if (CONV) {
+            if constexpr (C32) {
+                const bool hb = (xpix[i] & 1) != 0;
+                const int ih = (xpix[i] >> 20) + (hb ? stkh2 : stkh), iw = ((xpix[i] << 12) >> 20) + (hb ? stkw2 : stkw);
+                const bool ok = (hb ? skin2 : skin) && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
+                src = ok ? xsrc[i] + (hb ? stapoff2 : stapoff) : zeros;
+            } else if (CONV) {
                 const int ih = (xpix[i] >> 20) + stkh, iw = ((xpix[i] << 12) >> 20) + stkw;
                 const bool ok = skin && (unsigned)ih < (unsigned)a.g.H && (unsigned)iw < (unsigned)a.g.W;
                 src = ok ? xsrc[i] + stapoff : zeros;
@@ -1096,12 +1116,12 @@ static hipError_t ensure_lds_attr(K kernel, size_t lds, int device, bool* flags)
     return hipSuccess;
 }
 
-template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false, int XE = 0>
+template <bool W2, bool CONV, int MI, int WM, int WN, bool SPR = false, int XE = 0, bool C32 = false>
 static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStream_t s) {
     static bool attr_set[MAX_DEV] = {};
     constexpr int BM = 16 * MI * WM, BN = 64 * WN;
     constexpr size_t lds = 2 * (size_t)(BM * 128 + BN * 128 * (W2 ? 2 : 1));
-    hipError_t e = ensure_lds_attr(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE>, lds, o.device, attr_set);
+    hipError_t e = ensure_lds_attr(gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE, C32>, lds, o.device, attr_set);
     if (e != hipSuccess) return e;
     if (!o.zeros) return hipErrorInvalidValue;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
@@ -1122,7 +1142,7 @@ static hipError_t launch_glds_cfg(const GemmArgs& a, const EngineOpts& o, hipStr
     const int last_round = tiles % o.num_cu;
     const int stagger = o.gemm_stagger < 0 ? 0 : o.gemm_stagger > 0 ? o.gemm_stagger
                         : (!CONV && !o.lanes_active && tiles > o.num_cu && 2 * last_round < o.num_cu ? 300 : 0);
-    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
+    hipLaunchKernelGGL((gemm_glds_kernel<W2, CONV, MI, WM, WN, false, SPR, XE, C32>), dim3((unsigned)grid), dim3(512), lds, s, a, nt, tiles, o.zeros,
                        o.gemm_counted | (stagger << 8), o.gemm_tl);
     if (o.gemm_tl) dump_timeline(o, s, CONV ? "conv" : "linear");
     return hipGetLastError();
@@ -1272,8 +1292,12 @@ hipError_t launch_gemm(const GemmArgs& a, bool conv, const EngineOpts& o, hipStr
     if (a.a_tiled && (conv || narrow || !o.gemm_glds || a.K != 512 || a.M < 128 || a.N % 128)) return hipErrorInvalidValue;   // LDS-DMA kernel only
     if (conv) {
         if (a.res) return hipErrorInvalidValue;          // the conv instances are compiled without the residual path
-        if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
         const bool coords_ok = a.g.H + a.g.PH < 2048 && a.g.W + a.g.PW < 2048 && a.M < (1 << 24);      // packed pixel coordinates / rowmap entries
+        // C = 32 -> N = 64 (the second audio conv): its own LDS-DMA instance, 256x64 tiles (round 5; before: the register-staged kernel)
+        if (o.gemm_glds && !w2 && a.N == 64 && a.g.C == 32 && a.K % 32 == 0 && a.K == a.g.KH * a.g.KW * 32 && !a.g.tap_table && !a.g.rowmap && a.M >= 256 &&
+            coords_ok && a.out16 && !a.out32 && (a.ldc & 7) == 0 && (a.ldw & 7) == 0)
+            return launch_glds_cfg<false, true, 2, 8, 1, false, 0, true>(a, o, s);
+        if (narrow) return w2 ? launch_variant<4, 1, true, true>(a, s) : launch_variant<4, 1, true, false>(a, s);
         if (o.gemm_glds && a.M >= 256 && a.g.C % 64 == 0 && a.N % 128 == 0 && coords_ok) return w2 ? launch_glds<true, true>(a, o, s) : launch_glds<false, true>(a, o, s);
         if (a.g.rowmap) return hipErrorInvalidValue;          // only the LDS-DMA kernel knows the compaction
         return w2 ? launch_variant<2, 2, true, true>(a, s) : launch_variant<2, 2, true, false>(a, s);

@@ -110,6 +110,74 @@ __global__ __launch_bounds__(512) void kloop(const f16* __restrict__ A, const f1
                 }
             }
         }
+    } else if constexpr (V == 8 || V == 9) {
+        // Round 5: ASYMMETRIC issue -- only waves 0-3 (one per SIMD) issue LDS-DMA, 16 pieces each (their own 8 and those of wave + 4);
+        // waves 4-7 run MFMAs and fragment reads only, so every SIMD has one wave that never stalls on a DMA issue.
+        // V8: one piece per MFMA group (16 groups per k-tile), V9: all 16 in a burst behind the barrier.
+        constexpr int XB = BM * 128, STAGE = XB + BN * 128;
+        const int lrow = lane >> 3, pc = lane & 7;
+        const int fsw = (frow >> 1) & 7;
+        const int nk = K / 64;
+        const f16* xs[8]; const f16* ws[8];
+        auto setup = [&](int tile) {
+            const int n0 = (tile % n_tiles) * BN, m0 = (tile / n_tiles) * BM;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int vw = (wave & 3) + 4 * (i >> 2);
+                const int row = (vw * 4 + (i & 3)) * 8 + lrow;
+                const int c = pc ^ ((row >> 1) & 7);
+                xs[i] = A + (long)(m0 + row) * K + c * 8;
+                ws[i] = W + (long)(n0 + row) * K + c * 8;
+            }
+        };
+        auto piece = [&](int p, int kt, int buf) __attribute__((always_inline)) {      // p = 0..15: x pieces 0..7, w pieces 8..15
+            char* base = smem + buf * STAGE;
+            const int i = p & 7;
+            const int vw = (wave & 3) + 4 * (i >> 2);
+            if (p < 8) __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs[i] + kt * 64), (lds_ptr_t)(base + (vw * 4 + (i & 3)) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws[i] + kt * 64), (lds_ptr_t)(base + XB + (vw * 4 + (i & 3)) * 1024), 16, 0, 0);
+        };
+        const bool issuer = wave < 4;
+        int gk = 0;
+        if (issuer) {
+            setup(tile_of(0));
+#pragma unroll
+            for (int p = 0; p < 16; ++p) piece(p, 0, 0);
+        }
+        for (int r = 0; r < rounds; ++r) {
+            for (int kt = 0; kt < nk; ++kt, ++gk) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                const bool last = kt + 1 == nk;
+                if (issuer && last) setup(tile_of(r + 1));
+                const int nkt = last ? 0 : kt + 1;
+                if (V == 9 && issuer) {
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) piece(p, nkt, (gk + 1) & 1);
+                }
+                const char* sX = smem + (gk & 1) * STAGE;
+                const char* sW = sX + XB;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int choff = ((kk * 4 + fq) ^ fsw) << 4;
+                    auto ldx = [&](int j) -> f16x8 { return *reinterpret_cast<const f16x8*>(sX + (wm * 128 + j * 16 + frow) * 128 + choff); };
+                    f16x8 wf[4], xq[3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f16x8*>(sW + (wn * 64 + i * 16 + frow) * 128 + choff);
+                    xq[0] = ldx(0);
+                    xq[1] = ldx(1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xq[j % 3], acc[i][j], 0, 0, 0);
+                        if (j + 2 < 8) xq[(j + 2) % 3] = ldx(j + 2);
+                        if (V == 8 && issuer) piece(kk * 8 + j, nkt, (gk + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
     } else if constexpr (V == 0 || V == 1 || V == 6 || V == 7) {
         constexpr int XB = BM * 128, STAGE = XB + BN * 128;
         const int lrow = lane >> 3, pc = lane & 7;
@@ -297,6 +365,10 @@ int main(int argc, char** argv) {
     run<6>("V6 spread, the two waves of a SIMD issue in different halves", A, W, sink, M, N, K);
     run<7>("V7 bursts, waves 0-3 at the start / waves 4-7 at mid k-tile", A, W, sink, M, N, K);
     run<1>("V1 again", A, W, sink, M, N, K);
+    run<8>("V8 asymmetric: waves 0-3 issue all 16 pieces, one per MFMA group", A, W, sink, M, N, K);
+    run<9>("V9 asymmetric: waves 0-3 issue all 16 pieces in a burst", A, W, sink, M, N, K);
     run<0>("V0 again", A, W, sink, M, N, K);
+    run<8>("V8 again", A, W, sink, M, N, K);
+    run<1>("V1 again", A, W, sink, M, N, K);
     return 0;
 }
