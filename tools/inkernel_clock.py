@@ -63,6 +63,10 @@ dense = torch.randint(1, 256, masked.shape, dtype=torch.uint8, device="cuda")
 conv1_flop = 32 * 154 * 13904 * 64 * 735 * 2
 probe("conv1_direct (+ scan + edge fix), 32 masked clips", lambda: eng.debug_conv1_pool(masked, 4), "jg_clock_read_conv1", work=conv1_flop * 14 / 22)
 probe("conv1_direct (+ scan + edge fix), 32 dense clips", lambda: eng.debug_conv1_pool(dense, 4), "jg_clock_read_conv1", work=conv1_flop)
+smooth = torch.from_numpy(synth.synth_frames_structured(4100, 32, 150, "smooth")).cuda()
+probe("conv1_direct, 32 SMOOTH masked clips (low-contrast blobs + gradients, +-2 of pixel noise)", lambda: eng.debug_conv1_pool(smooth, 4), "jg_clock_read_conv1",
+      work=conv1_flop * 14 / 22)
+del smooth
 zeros = torch.zeros_like(masked)
 probe("conv1_direct, all-zero frames (every tile skipped: idle reference)", lambda: eng.debug_conv1_pool(zeros, 4), "jg_clock_read_conv1")
 del dense, zeros
