@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=5, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (the library default: needs a calibration), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16 (default here: calibration-free)")
+    ap.add_argument("--precision", type=int, default=5, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (opt-in: needs a calibration), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16 (the library default: calibration-free)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
@@ -647,9 +647,9 @@ def main():
             if extras.get("precision_modes"):
                 res["precision_modes"] = dict(extras["precision_modes"],
                                               what="the SAME timed loop (same clips, steps, two lanes) in the other precision treatments: `value` above is "
-                                                   "JG_PREC_FP16_RC (per-clip run-time correction, calibration-free: what the CLI drivers select for a "
-                                                   "checkpoint they have never seen); bc = JG_PREC_FP16_BC (corrections folded into the biases by a "
-                                                   "calibration pass: the library's default for the seeded weights, or with caller-supplied calibration clips), "
+                                                   "JG_PREC_FP16_RC (per-clip run-time correction, calibration-free: the library default and what the "
+                                                   "CLI drivers run every checkpoint in); bc = JG_PREC_FP16_BC (corrections folded into the biases by a "
+                                                   "calibration pass: opt-in, here with its built-in clips), "
                                                    "w2 = JG_PREC_FP16_W2 (hi+lo Linear weights, calibration-free)")
             if "pcie_clips_per_s" in extras:
                 res["pcie_inclusive"] = {"value": extras["pcie_clips_per_s"], "unit": "clips/s",

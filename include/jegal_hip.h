@@ -33,9 +33,10 @@ enum {
     JG_PREC_FP16 = 0,     /* every GEMM/conv operand fp16 */
     JG_PREC_FP16_W2 = 1,  /* Linear weights carried as hi+lo fp16 pair (2 MFMAs) */
     JG_PREC_FP16_W2_ALL = 2, /* conv weights split as well */
-    JG_PREC_FP16_BC = 3,  /* default: single fp16 weights on the gesture path, the systematic part of the weight
+    JG_PREC_FP16_BC = 3,  /* single fp16 weights on the gesture path, the systematic part of the weight
                              rounding error (w - fp16(w)).E[x] folded into the bias by a calibration pass run inside
-                             jg_finalize_weights; content-path Linears keep the hi+lo split */
+                             jg_finalize_weights (built-in clips: validated on the seeded weights only) or by jg_calibrate_gesture on
+                             the caller's clips; content-path Linears keep the hi+lo split.  Opt-in: ~3 % faster than the default */
     JG_PREC_BF16 = 4,     /* REPORTED mode (north_star names bf16): every weight and every 16-bit activation is bf16 and every
                              MFMA is a bf16 MFMA (v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16, the second build of the kernels,
                              namespace bf).  Same MFMA rate as fp16, 8 instead of 11 significant bits: the embeddings come out
@@ -43,7 +44,7 @@ enum {
                              (tests/test_gpu_precision_uploads.py::test_precision_modes_report prints the measured errors side by
                              side).  conv1 runs as an implicit GEMM over stacked frames and the LayerNorms as separate kernels in
                              this mode (the fused u8 conv1 kernel and the fp16 + fp8 token stream are fp16 constructs). */
-    JG_PREC_FP16_RC = 5   /* run-time corrected: as JG_PREC_FP16_BC, but the term (w - fp16(w)).E[x] of every GestSync transformer
+    JG_PREC_FP16_RC = 5   /* DEFAULT (round 5).  Run-time corrected: as JG_PREC_FP16_BC, but the term (w - fp16(w)).E[x] of every GestSync transformer
                              Linear is rebuilt per GEMM call and per clip from a fixed sample of THAT clip's own input rows (two small
                              launches in front of the GEMM, a per-clip bias in its epilogue) -- no calibration pass, nothing depends on
                              calibration data or on the other clips of a batch.  The JEGAL branch and the content path run hi+lo.

@@ -124,7 +124,7 @@ class Engine:
         if rc != 0:
             raise JegalError(f"jg_create({device_index}) failed with {rc}")
         self.h = h
-        self.precision = PREC_FP16_BC              # the library's default (jg_handle::precision)
+        self.precision = PREC_FP16_RC              # the library's default (jg_handle::precision)
         if precision is not None:
             self.set_precision(precision)
         self.finalized = 0

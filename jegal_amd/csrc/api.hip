@@ -105,7 +105,7 @@ struct jg_handle {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::string err;
-    int precision = JG_PREC_FP16_BC;
+    int precision = JG_PREC_FP16_RC;      // the calibration-free mode (round 5; rounds 1-4: JG_PREC_FP16_BC)
     bool bf16 = false;             // precision == JG_PREC_BF16: every launcher comes from the bf16 build (namespace bf)
     bool calib = false;            // calibration pass in progress (bc layers use hi+lo and record input means)
     bool gs_calibrated = false, jg_calibrated = false;

@@ -41,29 +41,29 @@ def load_checkpoint(path, kind):
 
 def _add_precision_args(p):
     p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3, 5],
-                   help="engine precision mode (include/jegal_hip.h); default: 3 (bias-corrected fp16) for the seeded synthetic "
-                        "weights or when --calibrate_frames is given, 5 (run-time corrected fp16: per-clip, calibration-free) for real checkpoints")
+                   help="engine precision mode (include/jegal_hip.h); default: 5 (run-time corrected fp16: per-clip, calibration-free), "
+                        "or 3 (bias-corrected fp16, ~3 %% faster) when --calibrate_frames is given")
     p.add_argument("--calibrate_frames", default=None,
                    help=".npy of masked uint8 crops (B,T,270,480,3) or (T,270,480,3): re-run the precision-mode-3 calibration on them")
 
 
-#: engine precision mode (include/jegal_hip.h) a driver selects for a checkpoint it has never seen, unless calibration clips are
-#: supplied: calibration-free by construction.  tests/test_gpu_weight_families.py holds THIS mode to 1e-3 on every weight family.
+#: engine precision mode (include/jegal_hip.h) a driver selects unless calibration clips are supplied: the library's default,
+#: calibration-free by construction.  tests/test_gpu_weight_families.py holds THIS mode to 1e-3 on every weight family.
 REAL_CHECKPOINT_PRECISION = 5          # PREC_FP16_RC: per-clip run-time correction (round 5; rounds 3-4: 1 = PREC_FP16_W2, 1.4x slower)
 
 
 def pick_precision(args, checkpoints, can_calibrate=True):
-    """The library's default precision mode folds (w - fp16(w)).E[x] into every Linear bias, with E[x] recorded on built-in synthetic
-    clips.  That calibration was only ever validated on the synthetic weights (no checkpoints ship with the reference), so a REAL
-    checkpoint gets the calibration-free run-time corrected mode (E[x] per clip from the clip's own rows, JG_PREC_FP16_RC; held to
-    1e-3 on every weight family by tests/test_gpu_weight_families.py) unless the caller supplies calibration clips (INTEGRATION.md
-    section 6) AND the command can run the calibration on them (can_calibrate: it needs the GestSync model, frames -> features -> JEGAL)."""
+    """Every checkpoint -- the seeded synthetic one included -- runs the library's default, the calibration-free run-time corrected
+    mode (E[x] per clip from the clip's own rows, JG_PREC_FP16_RC; held to 1e-3 on every weight family by
+    tests/test_gpu_weight_families.py).  The bias-corrected mode (JG_PREC_FP16_BC: the same term folded into the biases once, ~3 %
+    faster) is chosen only when the caller supplies calibration clips AND the command can run the
+    calibration on them (can_calibrate: it needs the GestSync model, frames -> features -> JEGAL); its built-in calibration on
+    synthetic clips was only ever validated on the seeded weights."""
     from ._lib import PREC_FP16_BC
     if getattr(args, "precision", None) is not None:
         return args.precision
-    real = any(c is not None and c != "synthetic" for c in checkpoints)
     calibrated = bool(getattr(args, "calibrate_frames", None)) and can_calibrate
-    return REAL_CHECKPOINT_PRECISION if real and not calibrated else PREC_FP16_BC
+    return PREC_FP16_BC if calibrated else REAL_CHECKPOINT_PRECISION
 
 
 def _models(args, need_gestsync=False, need_jegal=False):

@@ -215,7 +215,7 @@ def test_cli_drivers_pick_the_calibration_free_mode_for_real_checkpoints():
     from jegal_amd.drivers import pick_precision, REAL_CHECKPOINT_PRECISION
     from jegal_amd._lib import PREC_FP16_RC
     assert REAL_CHECKPOINT_PRECISION == PREC_FP16_RC == 5
-    assert pick_precision(NS(precision=None, calibrate_frames=None), ["synthetic", None]) == 3
+    assert pick_precision(NS(precision=None, calibrate_frames=None), ["synthetic", None]) == 5        # the library default, whatever the checkpoint
     assert pick_precision(NS(precision=None, calibrate_frames=None), ["/ckpt/gestsync.pth"]) == 5
     assert pick_precision(NS(precision=None, calibrate_frames="clips.npy"), ["/ckpt/gestsync.pth"]) == 3
     assert pick_precision(NS(precision=0, calibrate_frames=None), ["/ckpt/jegal.pth"]) == 0
