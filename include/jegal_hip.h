@@ -130,6 +130,13 @@ int jg_calibrate_xlmr(jg_handle* h, const int32_t* input_ids, const int32_t* att
  * (inference_embs.py:488-492) -> forward_vid -> mean(-1) (inference_embs.py:511) -> (B,T,1024) fp32.
  * The conv stack runs once over the padded clip (window de-duplication, exact). */
 int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, int T, float* out_feats);
+/* The same for a batch of clips of DIFFERENT lengths padded to T with copies of each clip's last frame (exact for the clip's own
+ * frames: inference_embs.py:283 edge-pads with the last frame and window t only reaches frame t + 12; this is how
+ * jegal_amd.drivers extract_gestsync_feats batches preprocess/extract_gestsync_feats.py:314-344, which runs one video at a time).
+ * valid_frames_host (host [B], 1..T): frames of clip b that are its own.  JG_PREC_FP16_RC takes each clip's run-time correction from
+ * its own rows only, so rows t < valid_frames[b] of clip b are bit-identical to the clip run alone and do not depend on T; the
+ * other modes ignore the lengths.  Rows t >= valid_frames[b] of the output are padding for the caller to strip. */
+int jg_gestsync_clip_ragged(jg_handle* h, const void* frames, int frames_dtype, int B, int T, const int32_t* valid_frames_host, float* out_feats);
 /* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,
  * pad = temporal edge padding (12 for clips, 0 for a raw 25-frame window) -> out (B*(T+2*pad-4),43,78,64) fp16 NHWC. */
 int jg_debug_conv1_pool(jg_handle* h, const void* frames_u8, int B, int T, int pad, void* out_f16);

@@ -32,6 +32,7 @@ _SIGS = {
     "jg_clear_staged_tensors": [_P],
     "jg_calibrate_gesture": [_P, _P, _I, _I, _I],
     "jg_gestsync_clip": [_P, _P, _I, _I, _I, _P],
+    "jg_gestsync_clip_ragged": [_P, _P, _I, _I, _I, ctypes.POINTER(ctypes.c_int32), _P],
     "jg_gestsync_windows": [_P, _P, _I, _P, _P],
     "jg_debug_conv1_pool": [_P, _P, _I, _I, _I, _P],
     "jg_debug_gemm": [_P, _I, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_double)],
@@ -230,12 +231,20 @@ class Engine:
         return out
 
     # ---- GestSync
-    def gestsync_clip(self, frames):
-        """frames (B,T,270,480,3) uint8 or float32 cuda tensor -> (B,T,1024) fp32."""
+    def gestsync_clip(self, frames, lengths=None):
+        """frames (B,T,270,480,3) uint8 or float32 cuda tensor -> (B,T,1024) fp32.  lengths (B ints, optional): frames of each clip
+        that are its own in a batch padded to T with copies of the clips' last frames (jg_gestsync_clip_ragged): rows t < lengths[b]
+        of clip b are then what the clip gives alone, whatever T is."""
         self._bind_stream()
         frames, code, B, T = self._frames_arg(frames)
         out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)
-        self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
+        if lengths is None:
+            self._ck(self.lib.jg_gestsync_clip(self.h, _ptr(frames), code, B, T, _ptr(out)))
+            return out
+        v = [int(x) for x in lengths]
+        if len(v) != B:
+            raise ValueError("lengths needs one entry per clip")
+        self._ck(self.lib.jg_gestsync_clip_ragged(self.h, _ptr(frames), code, B, T, (ctypes.c_int32 * B)(*v), _ptr(out)))
         return out
 
     def debug_gemm(self, M, N, K, mode=0, iters=10, a16=None, w16=None):

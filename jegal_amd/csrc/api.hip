@@ -166,6 +166,8 @@ struct jg_handle {
     size_t feats_cap = 0;
     std::vector<int32_t> audio_valid[4];   // host copies of the last four jg_jegal_audio_ragged calls' valid lengths (sources of stream-ordered uploads)
     unsigned audio_valid_next = 0;
+    std::vector<int32_t> clip_valid[8];    // ... and of the last eight jg_gestsync_clip_ragged parts' valid row counts
+    unsigned clip_valid_next = 0;
     // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
@@ -566,6 +568,7 @@ struct Epi {
     int calib_rows = 0;           // calibration pass: only the first calib_rows rows of A are real (0: all M) -- short XLM-R batches are padded to 128 rows
     // JG_PREC_FP16_RC: the M rows are rc_clips clips of rc_rpc rows each (0: no clip structure -> a run-time corrected layer runs hi+lo)
     int rc_rpc = 0, rc_clips = 0;
+    const int* rc_valid = nullptr;    // device [rc_clips]: rows of each clip that are its own (jg_gestsync_clip_ragged) or nullptr
 };
 
 int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, const Epi& e, const ConvGeom* g = nullptr) {
@@ -586,7 +589,7 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
             float *scr, *bc;
             RET(wsalloc(h, rc_scratch_elems(e.rc_clips, L.K), &scr));
             RET(wsalloc(h, (size_t)e.rc_clips * L.N, &bc));
-            RET(timed(h, JG_ST_GEMM, [&] { return launch_rc_bias(A, lda, e.a_tiled, e.rc_clips, e.rc_rpc, L.wl_calib, L.bias, L.N, L.K, scr, bc, h->stream); }));
+            RET(timed(h, JG_ST_GEMM, [&] { return launch_rc_bias(A, lda, e.a_tiled, e.rc_clips, e.rc_rpc, e.rc_valid, L.wl_calib, L.bias, L.N, L.K, scr, bc, h->stream); }));
             a.bias_clip = bc; a.rpc = e.rc_rpc; a.nclips = e.rc_clips;
         } else {
             a.Wl = L.wl_calib;
@@ -799,7 +802,7 @@ struct Qkv0 {
 };
 
 // rc_clips > 0: the rows are rc_clips clips of M / rc_clips rows each (the clip path; JG_PREC_FP16_RC's per-clip corrections)
-int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled, const Qkv0* q0 = nullptr, int rc_clips = 0) {
+int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool tiled, const Qkv0* q0 = nullptr, int rc_clips = 0, const int* rc_valid = nullptr) {
     const int M = nseq * S;
     const int rc_rpc = rc_clips > 0 && tiled ? M / rc_clips : 0;
     if (!rc_rpc) rc_clips = 0;
@@ -827,7 +830,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             RET(timed(h, JG_ST_ATTN, [&] { return launch_attention_gather(qpos, ag, nseq, S, 8, att, h->stream); }));
         } else {
             Epi e;
-            e.out16 = qkv; e.a_tiled = tiled; e.rc_rpc = rc_rpc; e.rc_clips = rc_clips;
+            e.out16 = qkv; e.a_tiled = tiled; e.rc_rpc = rc_rpc; e.rc_clips = rc_clips; e.rc_valid = rc_valid;
             RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.qkv, e));
             RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, nullptr, nseq, S, 8, 64, att, h->opts, h->stream); }));
         }
@@ -838,7 +841,7 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
             if (tiled) {
                 r.res16 = x16; r.out16 = x16; r.ln = &ln; r.ln_flavour = LN_STD;
                 if (h->stream8) { r.res8 = d8; r.out8 = d8; }
-                r.rc_rpc = rc_rpc; r.rc_clips = rc_clips;
+                r.rc_rpc = rc_rpc; r.rc_clips = rc_clips; r.rc_valid = rc_valid;
                 return gemm(h, JG_ST_GEMM, A, lda, M, W, r);
             }
             r.res = x32; r.ldr = 512; r.out32 = x32;
@@ -847,14 +850,16 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
         };
         RET(proj_ln(att, 512, L.out, L.n1));
         Epi f;
-        f.relu = 1; f.out16 = hid; f.a_tiled = tiled; f.rc_rpc = rc_rpc; f.rc_clips = rc_clips;
+        f.relu = 1; f.out16 = hid; f.a_tiled = tiled; f.rc_rpc = rc_rpc; f.rc_clips = rc_clips; f.rc_valid = rc_valid;
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, L.ff1, f));
         RET(proj_ln(hid, 2048, L.ff2, L.n2));
     }
     return JG_OK;
 }
 
-int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_feats) {
+// valid_host (optional, host [B]): clip b's first valid_host[b] frames are its own, the rest of its T frames is batch padding (copies of its
+// last frame, jg_gestsync_clip_ragged): only the run-time corrected mode looks at it -- a clip's statistics come from its own rows
+int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_feats, const int32_t* valid_host = nullptr) {
     if (!h->gs_ready) JG_FAIL(h, JG_ERR_STATE, "GestSync weights not finalized");
     if (B <= 0 || T <= 0) JG_FAIL(h, JG_ERR_ARG, "B and T must be positive");
     if (dtype != JG_U8 && dtype != JG_F32) JG_FAIL(h, JG_ERR_ARG, "frames dtype must be JG_U8 or JG_F32");
@@ -876,6 +881,14 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         const int nseq = nb * T, M = nseq * S;
         float* x32; f16 *x16, *hid, *mean16, *conv16 = nullptr;
         const bool tiled = gs_fused_plan(h, M);
+        int* rc_valid = nullptr;
+        if (valid_host && tiled && h->precision == JG_PREC_FP16_RC) {
+            std::vector<int32_t>& hv = h->clip_valid[h->clip_valid_next++ & 7];      // stays alive for seven more parts: the copy is stream-ordered
+            hv.resize(nb);
+            for (int b = 0; b < nb; ++b) hv[b] = valid_host[b0 + b] * S;              // rows = frames x 21 tokens
+            RET(wsalloc(h, (size_t)nb, &rc_valid));
+            HIPCHK(h, hipMemcpyAsync(rc_valid, hv.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, h->stream));
+        }
         // layer-0 qkv from the distinct conv positions: worth it when the windows overlap (T > 1) and the MFMA attention runs
         const bool lin0 = tiled && h->qkv0_linear && h->opts.attn_mfma && T > 1;
         if (lin0) RET(wsalloc(h, (size_t)nb * P * 512, &conv16));
@@ -884,11 +897,11 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(wsalloc(h, pad128(M) * 512, &x16));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
         const Qkv0 q0 = {conv16, nb, P, T, 12 - PAD};
-        RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr, nb));
+        RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr, nb, rc_valid));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)nseq * 512, &mean16));
         Epi f; f.relu = 1; f.out16 = hid; f.a_tiled = tiled;
-        if (tiled) { f.rc_rpc = T * S; f.rc_clips = nb; }
+        if (tiled) { f.rc_rpc = T * S; f.rc_clips = nb; f.rc_valid = rc_valid; }
         RET(gemm(h, JG_ST_GEMM, x16, 512, M, h->ff0, f));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_group_mean, hid, nseq, S, 512, mean16, h->stream); }));
         Epi o; o.out32 = out_feats + (size_t)b0 * T * 1024;
@@ -1676,6 +1689,19 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int dtype, int B, int T, 
     return run_in_lanes(h, B, T, [&](int b0, int nb) -> int {
         return gestsync_clip_impl(h, reinterpret_cast<const char*>(frames) + (size_t)b0 * T * FH * FW * 3 * esz, dtype, nb, T,
                                   out + (size_t)b0 * T * 1024);
+    });
+}
+
+int jg_gestsync_clip_ragged(jg_handle* h, const void* frames, int dtype, int B, int T, const int32_t* valid_frames_host, float* out) {
+    ENTER(h);
+    if (!frames || !out || !valid_frames_host) JG_FAIL(h, JG_ERR_ARG, "null buffer");
+    if (B <= 0 || T <= 0 || (dtype != JG_U8 && dtype != JG_F32)) return gestsync_clip_impl(h, frames, dtype, B, T, out);      // reports the error
+    for (int b = 0; b < B; ++b)
+        if (valid_frames_host[b] < 1 || valid_frames_host[b] > T) JG_FAIL(h, JG_ERR_ARG, "valid_frames[%d] = %d outside 1..T = %d", b, valid_frames_host[b], T);
+    const size_t esz = dtype == JG_U8 ? 1 : 4;
+    return run_in_lanes(h, B, T, [&](int b0, int nb) -> int {
+        return gestsync_clip_impl(h, reinterpret_cast<const char*>(frames) + (size_t)b0 * T * FH * FW * 3 * esz, dtype, nb, T,
+                                  out + (size_t)b0 * T * 1024, valid_frames_host + b0);
     });
 }
 

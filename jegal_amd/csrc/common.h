@@ -280,8 +280,9 @@ hipError_t launch_col_sum(const f16* A, long lda, int M, int K, float* scratch, 
 size_t col_sum_scratch_elems(int K);
 // JG_PREC_FP16_RC: out[c][n] = bias[n] + sum_k lo[n][k] * (mean over a fixed sample of clip c's rows of A[.][k]); clip c = rows c*rpc .. +rpc-1 of
 // A (row-major [.][lda], or the tiled fp16 token plane when `tiled`: K == 512); scratch: rc_scratch_elems(nclips, K) floats
-hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const f16* lo, const float* bias, int N, int K, float* scratch,
-                          float* out, hipStream_t s);
+// valid_rows (optional, device [nclips]): rows of each clip that are its own (the rest of its rpc rows is batch padding)
+hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const int* valid_rows, const f16* lo, const float* bias, int N, int K,
+                          float* scratch, float* out, hipStream_t s);
 size_t rc_scratch_elems(int nclips, int K);
 hipError_t launch_ragged_mean(const float* x, const int32_t* offsets, int n, int D, float* out, hipStream_t s);
 hipError_t launch_sim_rank(const float* e1, const float* e2, int n_local, int n_total, int row_offset, int D,

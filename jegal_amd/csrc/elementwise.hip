@@ -714,15 +714,20 @@ __device__ __forceinline__ int rc_rows_sampled(int rpc) {
     for (int r0 = 0; r0 < rpc; r0 += 128) cnt += rpc - r0 < 16 ? rpc - r0 : 16;
     return cnt;
 }
-__global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc, int K, f16* __restrict__ mean) {
+// valid (optional, device [nclips]): clip c's first valid[c] rows are its own (a batch padded to a common length: the rest is padding that
+// must not enter the clip's statistics); the sample is then defined on the clip's OWN row count, exactly as if it were alone.
+__global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict__ A, long lda, int tiled, int rpc_all, const int* __restrict__ valid, int K,
+                                                          f16* __restrict__ mean) {
     __shared__ float red[32][8 * 8 + 1];
     const int clip = blockIdx.x, t = threadIdx.x;
     const int cg = t & 7, rl = t >> 3;                          // 8 column groups of 8 (a 64-column slab) x 32 row lanes
     const int n = blockIdx.y * 64 + cg * 8;
+    int rpc = rpc_all;                                          // rows of this clip that count
+    if (valid) rpc = valid[clip] < 1 ? 1 : (valid[clip] < rpc_all ? valid[clip] : rpc_all);
     const int step = rpc < 1024 ? 16 : 128;                     // 16-row runs: every one, or every eighth
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto row_ptr = [&](int r) -> const f16* {
-        const long m = (long)clip * rpc + r;
+        const long m = (long)clip * rpc_all + r;
         return tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
                      : A + m * lda + n;
     };
@@ -795,12 +800,12 @@ __global__ __launch_bounds__(256) void rc_gemv_kernel(const f16* __restrict__ me
 
 size_t rc_scratch_elems(int nclips, int K) { return (size_t)nclips * K; }
 
-hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const f16* lo, const float* bias, int N, int K, float* scratch,
-                          float* out, hipStream_t s) {
+hipError_t launch_rc_bias(const f16* A, long lda, int tiled, int nclips, int rpc, const int* valid_rows, const f16* lo, const float* bias, int N, int K,
+                          float* scratch, float* out, hipStream_t s) {
     if (nclips <= 0 || rpc <= 0) return hipSuccess;
     if ((K != 512 && K != 2048) || (tiled && K != 512) || (N & 31)) return hipErrorInvalidValue;
     f16* mean16 = reinterpret_cast<f16*>(scratch);
-    hipLaunchKernelGGL(rc_col_mean_kernel, dim3(nclips, K / 64), dim3(256), 0, s, A, lda, tiled, rpc, K, mean16);
+    hipLaunchKernelGGL(rc_col_mean_kernel, dim3(nclips, K / 64), dim3(256), 0, s, A, lda, tiled, rpc, valid_rows, K, mean16);
     hipLaunchKernelGGL(rc_gemv_kernel, dim3(N / 32, (nclips + 31) / 32), dim3(256), 0, s, mean16, lo, bias, nclips, N, K, out);
     return hipGetLastError();
 }

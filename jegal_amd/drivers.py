@@ -148,7 +148,8 @@ def cmd_extract_gestsync_feats(argv):
             fr = np.load(f)
             batch[i, :t] = fr
             batch[i, t:] = fr[t - 1]
-        feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device)).cpu().numpy()
+        # (the lengths keep each clip's run-time precision correction on its OWN frames: rows < t are those of the clip alone)
+        feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device), lengths=[t for t, _, _ in group]).cpu().numpy()
         return [feats[i, :t] for i, (t, _, _) in enumerate(group)]
 
     def save_one(feat, out):

@@ -39,13 +39,14 @@ class GestSync:
         with torch.no_grad():
             return self.engine.gestsync_windows(x, return_feats=return_feats)
 
-    def extract_clip_feats(self, frames):
+    def extract_clip_feats(self, frames, lengths=None):
         """frames (B,T,270,480,3) uint8 (or float in [0,1]) -> (B,T,1024): the padded/windowed loop of
-        inference_embs.py:283,476-522 with the conv stack de-duplicated across windows."""
+        inference_embs.py:283,476-522 with the conv stack de-duplicated across windows.  lengths (optional): each clip's own
+        frame count in a batch padded to T with copies of the clips' last frames (Engine.gestsync_clip)."""
         self._check()
         if frames.dim() == 4:
             frames = frames.unsqueeze(0)
         with torch.no_grad():
-            return self.engine.gestsync_clip(frames)
+            return self.engine.gestsync_clip(frames, lengths)
 
     __call__ = forward_vid

@@ -177,7 +177,8 @@ def test_ragged_batches_by_last_frame_padding_are_exact():
         for i, c in enumerate(clips):
             batch[i, :lens[i]] = c
             batch[i, lens[i]:] = c[-1]
-        return gs.extract_clip_feats(torch.from_numpy(batch).cuda()).cpu()
+        # (lengths: the run-time corrected default mode takes each clip's statistics from its own frames, as the driver does)
+        return gs.extract_clip_feats(torch.from_numpy(batch).cuda(), lengths=lens).cpu()
 
     out, out_longer = padded(max(lens)), padded(max(lens) + 7)
     for i, c in enumerate(clips):

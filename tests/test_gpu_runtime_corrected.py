@@ -128,3 +128,29 @@ def test_rc_odd_shapes_vs_oracle(rc, B, T, chunk):
         worst = max(worst, rel(feats[b], ref))
     print(f"\nRC B={B} T={T} chunk={chunk}: GestSync feats rel-L2 (worst of 3 clips) {worst:.3e}", end="")
     assert worst < TOL
+
+
+def test_rc_padded_batch_with_lengths_equals_the_clips_alone(rc):
+    """jg_gestsync_clip_ragged: clips of 60 and 75 frames padded to 90 with copies of their last frames (how the feature-extraction
+    driver batches).  With the lengths each clip's correction comes from its OWN rows: the kept rows are bit-identical to the clip
+    run alone and to another padding length; WITHOUT the lengths the padding rows enter the statistics (still within tolerance here,
+    but no longer the clip's own result)."""
+    lens = [60, 75]
+    clips = [synth.synth_frames(70 + i, 1, t)[0] for i, t in enumerate(lens)]
+
+    def padded(Tpad, with_lengths=True):
+        batch = np.empty((2, Tpad, 270, 480, 3), np.uint8)
+        for i, c in enumerate(clips):
+            batch[i, :lens[i]] = c
+            batch[i, lens[i]:] = c[-1]
+        return rc.gestsync_clip(torch.from_numpy(batch).cuda(), lengths=lens if with_lengths else None)
+    a, b, loose = padded(90), padded(101), padded(90, with_lengths=False)
+    for i, c in enumerate(clips):
+        alone = rc.gestsync_clip(torch.from_numpy(c[None]).cuda())[0]
+        assert torch.equal(a[i, :lens[i]], alone), i
+        assert torch.equal(b[i, :lens[i]], alone), i
+        d = rel(loose[i, :lens[i]], alone)
+        print(f"\nclip {i}: padded batch without lengths vs the clip alone: rel-L2 {d:.2e}", end="")
+        assert d < TOL
+    with pytest.raises(Exception):
+        rc.gestsync_clip(torch.from_numpy(clips[0][None]).cuda(), lengths=[61])          # beyond T
