@@ -174,6 +174,7 @@ struct jg_handle {
     bool dual_stream = true;
     int dual_split = 3;            // the first lane gets dual_split/8 of the batch
     int dual_split32 = 0;          // option "dual_split32" (experiments): the first lane gets this many 32nds of the batch instead (0: use dual_split)
+    int gesture_lanes = 0;         // option "gesture_lanes" (experiments): 3 / 4 = the gesture path runs as that many EQUAL parts (0: two lanes, dual_split)
     std::map<hipStream_t, Arena> ws_parked;      // arenas of the other streams this handle has been bound to (jg_set_stream)
     static constexpr int MAX_LANES = 4;
     hipStream_t lane_stream[MAX_LANES] = {};
@@ -1567,6 +1568,11 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "gesture_lanes")) {
+        if (value != 0 && (value < 2 || value > jg_handle::MAX_LANES)) JG_FAIL(h, JG_ERR_ARG, "gesture_lanes must be 0 or 2..%d", jg_handle::MAX_LANES);
+        h->gesture_lanes = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "xlmr_lanes")) {
         if (value < 1 || value > jg_handle::MAX_LANES) JG_FAIL(h, JG_ERR_ARG, "xlmr_lanes must be 1..%d", jg_handle::MAX_LANES);
         h->xl_lanes = value;
@@ -1920,7 +1926,7 @@ int jg_extract_gesture(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(jegal_gestures_impl(h, feats, nullptr, nb, T, 1, emb));
         return timed(h, JG_ST_MISC, [&] { return launch_l2norm(emb, emb, nb * T, 512, h->stream); });
     };
-    return run_in_lanes(h, B, T, run_part);
+    return run_in_lanes(h, B, T, run_part, h->gesture_lanes);
 }
 
 int jg_pool_mean(jg_handle* h, const float* x, const int32_t* off, int n, int D, float* out) {
