@@ -731,20 +731,33 @@ __global__ __launch_bounds__(256) void rc_col_mean_kernel(const f16* __restrict_
         return tiled ? A + (m >> 7) * 65536 + (long)(n >> 6) * 8192 + ((m & 127) >> 4) * 1024 + ((n & 63) >> 4) * 256 + (m & 15) * 16 + (n & 15)
                      : A + m * lda + n;
     };
-    // row lane rl takes row (rl & 15) of every second sampled run (runs of its parity rl >> 4); four loads in flight per thread (the
-    // loop is a latency chain otherwise), summed in a fixed order
+    // row lane rl takes row (rl & 15) of every second sampled run (runs of its parity rl >> 4); EIGHT loads in flight per thread (the
+    // rows were just written with nontemporal stores: every load is an HBM round trip, and a 150-frame clip gives a thread 13 rows),
+    // summed in a fixed order
     const int stride = 2 * step;
     int r = (rl & 15) + (rl >> 4) * step;
-    for (; r + 3 * stride < rpc; r += 4 * stride) {
-        const f16x8 v0 = *reinterpret_cast<const f16x8*>(row_ptr(r)), v1 = *reinterpret_cast<const f16x8*>(row_ptr(r + stride));
-        const f16x8 v2 = *reinterpret_cast<const f16x8*>(row_ptr(r + 2 * stride)), v3 = *reinterpret_cast<const f16x8*>(row_ptr(r + 3 * stride));
+    for (; r + 7 * stride < rpc; r += 8 * stride) {
+        f16x8 v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = (((acc[e] + (float)v0[e]) + (float)v1[e]) + (float)v2[e]) + (float)v3[e];
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f16x8*>(row_ptr(r + u * stride));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
     }
-    for (; r < rpc; r += stride) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(row_ptr(r));
+    {   // the tail: up to seven rows, again all in flight
+        f16x8 v[7];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        for (int u = 0; u < 7; ++u) {
+            const int ru = r + u * stride;
+            v[u] = *reinterpret_cast<const f16x8*>(row_ptr(ru < rpc ? ru : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+            if (r + u * stride < rpc) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+            }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
