@@ -364,3 +364,14 @@ def test_source_packer_layout():
     pk.reset()
     with pytest.raises(ValueError):
         pk.add(clips[0], -2)
+
+
+def test_importing_the_package_does_not_touch_the_environment():
+    """`import jegal_amd` used to set GPU_MAX_HW_QUEUES for the whole process (and its children).  Now an application calls
+    jegal_amd.want_hw_queues() before its first HIP call; the call never overrides the caller's own setting."""
+    import subprocess
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import jegal_amd; assert 'GPU_MAX_HW_QUEUES' not in os.environ; "
+            "assert jegal_amd.want_hw_queues() == '8' and os.environ['GPU_MAX_HW_QUEUES'] == '8'; "
+            "os.environ['GPU_MAX_HW_QUEUES'] = '4'; assert jegal_amd.want_hw_queues() == '4'; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
