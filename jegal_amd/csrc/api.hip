@@ -896,7 +896,7 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv, conv16));
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled ? (h->stream8 ? 1 : 2) : 0, x32, x16, h->stream); }));
         const Qkv0 q0 = {conv16, nb, P, T, 12 - PAD};
         RET(gs_transformer(h, x32, x16, nseq, S, tiled, lin0 ? &q0 : nullptr, nb, rc_valid));
         RET(wsalloc(h, (size_t)M * 512, &hid));
@@ -930,7 +930,7 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
         const bool tiled = gs_fused_plan(h, M);
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
-        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled, x32, x16, h->stream); }));
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled ? (h->stream8 ? 1 : 2) : 0, x32, x16, h->stream); }));
         RET(gs_transformer(h, x32, x16, nb, S, tiled));
         RET(wsalloc(h, (size_t)M * 512, &hid));
         RET(wsalloc(h, (size_t)M * 1024, &full));

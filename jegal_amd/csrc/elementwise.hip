@@ -175,17 +175,18 @@ __global__ __launch_bounds__(256) void window_gather_tiled_kernel(const float* _
     const float* src = conv + ((long)b * P + pp) * 512 + cb * 64 + 4 * ng;
     const float* pes = pe + (long)j * 512 + cb * 64 + 4 * ng;
     const long base = (rb >> 3) * 65536 + (long)cb * 8192 + (rb & 7) * 1024;
-    unsigned dq[4];
+    unsigned dq[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4 v = *reinterpret_cast<const f32x4*>(src + 16 * q);
         v += *reinterpret_cast<const f32x4*>(pes + 16 * q);
         const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
         if (live) __builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(x16 + base + q * 256 + m15 * 16 + 4 * ng));
-        dq[q] = res_enc4(v.x, v.y, v.z, v.w, h[0], h[1], h[2], h[3]);
+        if (d8) dq[q] = res_enc4(v.x, v.y, v.z, v.w, h[0], h[1], h[2], h[3]);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    if (live) __builtin_nontemporal_store(u32x4{dq[0], dq[1], dq[2], dq[3]}, reinterpret_cast<u32x4*>(d8 + base + lane * 16));
+    // (d8 == nullptr: the token stream is the fp16 plane alone, option stream_fp16)
+    if (live && d8) __builtin_nontemporal_store(u32x4{dq[0], dq[1], dq[2], dq[3]}, reinterpret_cast<u32x4*>(d8 + base + lane * 16));
 }
 
 hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P, int Twin, int L, int D, int shift, int tiled,
@@ -195,7 +196,7 @@ hipError_t launch_window_gather(const float* conv, const float* pe, int B, int P
         if ((long)B * Twin * L >= (1L << 31)) return hipErrorInvalidValue;
         const long nblk = (((long)B * Twin * L + 15) >> 4) * 8;
         hipLaunchKernelGGL(window_gather_tiled_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s, conv, pe, B, P, Twin, L, shift,
-                           reinterpret_cast<signed char*>(x32), x16);
+                           tiled == 2 ? nullptr : reinterpret_cast<signed char*>(x32), x16);          // tiled == 2: no correction plane
         return hipGetLastError();
     }
     const long total = (long)B * Twin * L * (D / 4);
