@@ -22,6 +22,10 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef JG_LNF_JD
+#define JG_LNF_JD 2            // LN-fused epilogue: 16-row block in front of which the next tile's first DMA is issued (experiments: 1 / 3 / 4)
+#endif
+
 JG_NS_BEGIN
 
 // epilogue activation (GemmArgs::relu): 0 none, 1 ReLU, 2 exact GELU 0.5 v (1 + erf(v / sqrt 2)) (XLM-RoBERTa's intermediate layer;
@@ -515,8 +519,11 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
         switch (pending) {
             case 8: wait_vmcnt<8>(); break;
             case 16: wait_vmcnt<16>(); break;
+            case 24: wait_vmcnt<24>(); break;
             case 32: wait_vmcnt<32>(); break;
+            case 40: wait_vmcnt<40>(); break;
             case 48: wait_vmcnt<48>(); break;
+            case 56: wait_vmcnt<56>(); break;
             case 60: wait_vmcnt<60>(); break;
             default: wait_vmcnt<0>(); break;
         }
@@ -691,7 +698,7 @@ src = xsrc[i] + ((!XE && a.a_tiled) ? (long)sk0 * 128 : (long)sk0);        // ti
             // HBM latency hides behind the rest of the epilogue); that tile's first DMA goes in front of block JD and
             // is retired with a counted wait.  Whole 128-row tiles are written: the planes hold ceil(M/128)*128 rows.
             // bias / gamma / beta come from LDS (3 x 512 floats, re-staged per tile: the k loop owns the LDS).
-            constexpr int JD = 2;                                         // row block in front of which the next tile's DMA goes
+            constexpr int JD = JG_LNF_JD;                                 // row block in front of which the next tile's DMA goes (default 2)
             float* red = reinterpret_cast<float*>(smem + STAGE);          // [2][8 waves][BM rows]
             float* lnp = red + 2 * 8 * BM;                                // [4][BN]: bias, gamma, beta, bias of the tile's second clip
             static_assert(BN == 512, "one parked element per thread");
