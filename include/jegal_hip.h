@@ -118,7 +118,7 @@ int jg_calibrate_gesture(jg_handle* h, const void* frames, int frames_dtype, int
  * Third-party arithmetic: parity is pinned against transformers.XLMRobertaModel with seeded random weights
  * (tests/golden/xlmr.npz), not against the released checkpoint, which is not available offline. */
 int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attention_mask, int B, int L, float* out);
-/* JG_PREC_FP16_BC only.  After jg_finalize_weights(h, 4) the XLM-RoBERTa Linears run with hi+lo fp16 weight pairs (calibration-free,
+/* JG_PREC_FP16_BC and JG_PREC_FP16_RC (the default).  After jg_finalize_weights(h, 4) the XLM-RoBERTa Linears run with hi+lo fp16 weight pairs (calibration-free,
  * two MFMAs per fragment pair).  This call runs one pass over the CALLER's token ids (device (B,L) int32; attention_mask may be
  * NULL), records the input mean of every Linear and switches them to single fp16 weights with the systematic rounding term
  * (w - fp16(w)).E[x] folded into the bias (~1.5x faster encoder).  input_ids == NULL: built-in uniform-random ids -- validated on
