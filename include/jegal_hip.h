@@ -84,6 +84,7 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and run the two parts concurrently on two internal
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
+ *   "num_cu"          workgroups a persistent kernel launches (default: the device's CU count; experiment)
  *   "gesture_lanes"   0 (default): two lanes split 3:5; 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a
  *                     kernel that reads a row nobody wrote (the row / band skips leave rows unwritten on purpose) shows up as NaN

@@ -1568,6 +1568,11 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "num_cu")) {          // experiments: persistent kernels of this handle launch this many workgroups (<= the device's CUs)
+        if (value < 8 || value > 1024) JG_FAIL(h, JG_ERR_ARG, "num_cu out of range");
+        o.num_cu = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "gesture_lanes")) {
         if (value != 0 && (value < 2 || value > jg_handle::MAX_LANES)) JG_FAIL(h, JG_ERR_ARG, "gesture_lanes must be 0 or 2..%d", jg_handle::MAX_LANES);
         h->gesture_lanes = value;
