@@ -3,8 +3,8 @@
 Every frames -> embedding oracle comparison of rounds 1-3 drew its clips from synth.synth_frames (noise under a 110-row mask) -- the
 distribution the default precision mode's bias corrections are calibrated on (api.hip, calibrate_impl).  The reference's inputs
 are natural crops (inference_embs.py:235-286): smooth, low contrast, saturated regions, a mask that follows the chin per frame.
-Three seeded families (synth.synth_frames_structured), two full-length clips each, default mode (JG_PREC_FP16_BC, calibrated on
-the built-in noise clips) and the calibration-free JG_PREC_FP16_W2, measured errors printed."""
+Three seeded families (synth.synth_frames_structured), two full-length clips each, in JG_PREC_FP16_BC (calibrated on the built-in
+noise clips), the calibration-free JG_PREC_FP16_W2 and the run-time corrected default JG_PREC_FP16_RC, measured errors printed."""
 import numpy as np
 import pytest
 import torch
@@ -29,11 +29,11 @@ def oracle_sd():
 
 @pytest.fixture(scope="module")
 def engines():
-    from jegal_amd._lib import Engine, PREC_FP16_BC, PREC_FP16_W2
+    from jegal_amd._lib import Engine, PREC_FP16_BC, PREC_FP16_W2, PREC_FP16_RC
     from jegal_amd.gestsync import GestSync
     from jegal_amd.jegal import JEGAL
     out = {}
-    for name, mode in (("fp16_bc", PREC_FP16_BC), ("fp16_w2", PREC_FP16_W2)):
+    for name, mode in (("fp16_bc", PREC_FP16_BC), ("fp16_w2", PREC_FP16_W2), ("fp16_rc", PREC_FP16_RC)):
         e = Engine(0, precision=mode)
         GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
         JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())

@@ -154,3 +154,18 @@ def test_rc_padded_batch_with_lengths_equals_the_clips_alone(rc):
         assert d < TOL
     with pytest.raises(Exception):
         rc.gestsync_clip(torch.from_numpy(clips[0][None]).cuda(), lengths=[61])          # beyond T
+
+
+def test_rc_long_clip_whole_path(rc):
+    """One 260-frame clip (longer than any AVS clip: 220) through the whole gesture path in the default mode: 5 460 token rows per
+    clip (the every-eighth-run sample: 43 runs), the JEGAL branch on the online-softmax attention (S = 260 > 160)."""
+    gsd, jsd = O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict())
+    T = 260
+    frames = synth.synth_frames(2600, 1, T)
+    emb = rc.extract_gesture(torch.from_numpy(frames).cuda()).cpu().numpy()
+    with torch.no_grad():
+        f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[0].astype(np.float32) / np.float32(255.0)))
+        g = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy()
+    r, mx = rel(emb[0], g), float(np.abs(emb[0] - g).max())
+    print(f"\nRC T = {T}: embedding rel-L2 {r:.3e} max-abs {mx:.3e}", end="")
+    assert r < TOL and mx < TOL
