@@ -44,11 +44,18 @@ enum {
                              (tests/test_gpu_precision_uploads.py::test_precision_modes_report prints the measured errors side by
                              side).  conv1 runs as an implicit GEMM over stacked frames and the LayerNorms as separate kernels in
                              this mode (the fused u8 conv1 kernel and the fp16 + fp8 token stream are fp16 constructs). */
-    JG_PREC_FP16_RC = 5   /* DEFAULT (round 5).  Run-time corrected: as JG_PREC_FP16_BC, but the term (w - fp16(w)).E[x] of every GestSync transformer
+    JG_PREC_FP16_RC = 5,  /* DEFAULT (round 5).  Run-time corrected: as JG_PREC_FP16_BC, but the term (w - fp16(w)).E[x] of every GestSync transformer
                              Linear is rebuilt per GEMM call and per clip from a fixed sample of THAT clip's own input rows (two small
                              launches in front of the GEMM, a per-clip bias in its epilogue) -- no calibration pass, nothing depends on
                              calibration data or on the other clips of a batch.  The JEGAL branch and the content path run hi+lo.
                              What the CLI drivers select for a checkpoint they have never seen (jegal_amd/drivers.py). */
+    JG_PREC_FP32 = 6      /* AUDIT mode (round 6; SURVEY 8b's precision list names BF16X3 / FP32: this is that exact mode).  Every GEMM /
+                             convolution on v_mfma_f32_32x32x2_f32 with fp32 weights, fp32 activations end to end, fp32 softmax and
+                             LayerNorm: the on-device stand-in for the reference's CPU path, which is fp32 (inference_embs.py:497: autocast
+                             does nothing without CUDA).  ~2e-6 of the fp32 oracle instead of ~6e-4, ~50 clips/s instead of ~2 600: what
+                             `python -m jegal_amd.drivers ... --audit` compares the default mode with on the caller's own clips and
+                             checkpoint, where no oracle exists.  Option "audit_weights" (before jg_finalize_weights) keeps the fp32
+                             matrices next to the fp16 ones in any mode, option "audit_stages" then moves single stages to fp32. */
 };
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -88,7 +95,11 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "gesture_lanes"   0 (default): two lanes split 3:5; 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a
  *                     kernel that reads a row nobody wrote (the row / band skips leave rows unwritten on purpose) shows up as NaN
- *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug) */
+ *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug)
+ *   "audit_weights"   1 (before jg_finalize_weights): the fp32 matrices are kept next to the packed fp16 ones (always in JG_PREC_FP32)
+ *   "audit_stages"    mask of the stages that run on the fp32 audit kernels (needs audit_weights): 1 GestSync conv stack, 2 GestSync
+ *                     transformer + ff_vid, 4 JEGAL gesture branch, 8 JEGAL content path (audio / text / fusion), 16 XLM-RoBERTa.  The
+ *                     stage boundaries are fp32 tensors in every mode; this is how DESIGN.md section 3 decomposes the fp16 error by stage */
 int jg_set_option(jg_handle* h, const char* name, int value);
 int jg_sync(jg_handle* h);
 

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjegal_hip.so")
 
 JG_F32, JG_F16, JG_I64, JG_U8 = 0, 1, 2, 3
-PREC_FP16, PREC_FP16_W2, PREC_FP16_W2_ALL, PREC_FP16_BC, PREC_BF16, PREC_FP16_RC = 0, 1, 2, 3, 4, 5
+PREC_FP16, PREC_FP16_W2, PREC_FP16_W2_ALL, PREC_FP16_BC, PREC_BF16, PREC_FP16_RC, PREC_FP32 = 0, 1, 2, 3, 4, 5, 6
+AUDIT_CONV, AUDIT_GESTSYNC, AUDIT_JEGAL, AUDIT_CONTENT, AUDIT_XLMR = 1, 2, 4, 8, 16      # option audit_stages (include/jegal_hip.h)
 STAGES = ["stack_frames", "conv1", "maxpool", "conv2-fc6+audio_cnn", "gemm", "attention", "layernorm", "misc", "conv1_aux"]
 
 _P = ctypes.c_void_p

@@ -5,6 +5,7 @@
 #include "common.h"
 #undef JG_BF16
 #include "../../include/jegal_hip.h"
+#include "audit32.h"
 
 #include <cmath>
 #include <cstdio>
@@ -67,6 +68,10 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     // sum_k wh[n][k] (x[k] - mean) rstd, and the bias correction covers the lo part) and of wh + lo (hi+lo runs)
     float* c1h = nullptr;
     float* c1f = nullptr;
+    // fp32 audit path (JG_PREC_FP32 / option audit_weights; audit32.hip): the fp32 matrix [N][K] as packed (BatchNorm folded, same k order as
+    // wh) and the layer's own fp32 bias (`bias` above may carry a calibration's correction)
+    float* w32d = nullptr;
+    float* b32d = nullptr;
 };
 struct LNp { float* w = nullptr; float* b = nullptr; };
 
@@ -180,6 +185,11 @@ struct jg_handle {
     hipStream_t lane_stream[MAX_LANES] = {};
     Arena lane_ws[MAX_LANES];
     hipEvent_t lane_ev[MAX_LANES + 1] = {};      // [0]: the caller's stream at entry, [1 + l]: end of lane l
+    // fp32 audit path (audit32.hip).  audit_weights: finalize also keeps every matrix in fp32 (always in JG_PREC_FP32); audit_stages: which
+    // stages of the path run in fp32 (bit 0 conv stack, 1 GestSync transformer + ff_vid, 2 JEGAL gesture branch, 3 JEGAL content path,
+    // 4 XLM-RoBERTa; JG_PREC_FP32 = all of them) -- the stage boundaries are fp32 tensors in every mode, so stages can be mixed
+    bool audit_weights = false;
+    int audit_stages = 0;
     int xl_lanes = 2;              // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams
 };
 
@@ -333,6 +343,11 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     L->wl = nullptr;
     if (split) RET(upload(h, lo, &L->wl));
     RET(upload(h, bias, &L->bias));
+    L->w32d = L->b32d = nullptr;
+    if (h->audit_weights || h->precision == JG_PREC_FP32) {
+        RET(upload(h, w, &L->w32d));
+        RET(upload(h, bias, &L->b32d));
+    }
     L->bc = bc;
     L->rc = rc;
     L->bc_pending = false;
@@ -783,8 +798,13 @@ int gs_build_const_chain(jg_handle* h) {
 // Whether the whole GestSync transformer of M tokens runs with residual+LayerNorm fused into the projection GEMMs.
 // All twelve projections must qualify (single-fp16 weights, not the calibration pass): the fused kernel keeps the
 // fp32 residual stream in its own tiled order (gemm.hip), so fused and unfused layers cannot be mixed.
-bool gs_fused_plan(const jg_handle* h, int M) {
+// rows_per_clip: rows of one clip in the launch (T * 21 on the clip path; 0: no clip structure, e.g. forward_vid windows).  In the
+// run-time corrected mode the LayerNorm-fused projections exist with the per-clip bias only (there is no hi+lo instance of that
+// kernel), and the per-clip bias needs rows_per_clip >= 256 (gemm(): `can`): shorter clips (T <= 12) and launches without clip structure
+// take the unfused plan, whose GEMMs run hi+lo (such batches used to fail with hipErrorInvalidValue).
+bool gs_fused_plan(const jg_handle* h, int M, int rows_per_clip) {
     if (!h->fuse_ln || !h->opts.gemm_glds || h->calib || M < 1024 || h->bf16) return false;     // (the token stream's codec is fp16 + fp8)      // the tiled token stream is read by LDS-DMA only
+    if (h->precision == JG_PREC_FP16_RC && rows_per_clip < 256) return false;
     for (int l = 0; l < 6; ++l)
         if (h->gs_layers[l].out.wl || h->gs_layers[l].ff2.wl) return false;
     return true;
@@ -858,6 +878,261 @@ int gs_transformer(jg_handle* h, float* x32, f16* x16, int nseq, int S, bool til
     return JG_OK;
 }
 
+// ------------------------------------------------------------------------------------ fp32 audit path (audit32.hip)
+// JG_PREC_FP32 (and option audit_stages on a handle finalized with audit_weights): the same stages as above on fp32 weights and fp32
+// activations, exact-fp32 MFMAs, fp32 softmax / LayerNorm.  The reference's CPU path is fp32 (inference_embs.py:497 -- autocast does nothing
+// without CUDA): this is the on-device stand-in for it, what the fp16 modes are audited against on a checkpoint the parity tests never saw.
+// Straightforward on purpose (no window de-duplication tricks beyond the distinct conv positions, no fused epilogues beyond bias /
+// residual / activation, the mean(-1) AFTER ff_vid.2 as in inference_embs.py:511); ~40-60 clips/s.
+enum { AUD_CONV = 1, AUD_GS = 2, AUD_JG = 4, AUD_CONTENT = 8, AUD_XLMR = 16, AUD_ALL = 31 };
+inline int audit_mask(const jg_handle* h) { return h->precision == JG_PREC_FP32 ? AUD_ALL : h->audit_stages; }
+
+struct Epi32 {
+    const float* res = nullptr;
+    long ldr = 0;
+    int res_mod = 0;
+    int act = 0;          // 0 none, 1 ReLU, 2 exact GELU
+};
+
+int gemm32(jg_handle* h, int stage, const float* A, long lda, int M, const Lin& L, float* out, const Epi32& e = Epi32(), const ConvGeom* g = nullptr) {
+    if (!L.w32d || !L.b32d)
+        JG_FAIL(h, JG_ERR_STATE, "fp32 audit weights missing: select JG_PREC_FP32 or set option audit_weights=1 before jg_finalize_weights");
+    Gemm32Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda;
+    if (g) { a.g = *g; a.conv = 1; }
+    a.W = L.w32d; a.ldw = L.K;
+    a.M = M; a.N = L.N; a.K = L.K;
+    a.bias = L.b32d;
+    a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
+    a.out = out; a.ldc = L.N;
+    a.act = e.act;
+    return timed(h, stage, [&] { return launch_gemm32(a, h->stream); });
+}
+
+// conv stack over `nclip` temporal volumes -> conv_out (nclip*P, 512) fp32 (gestsync.py:34-87,308-325: conv + BatchNorm(eval, folded) + ReLU, two max-pools)
+int gs_conv_stack32(jg_handle* h, const void* src, int src_u8, long sb, long st, long sh, long sw, long sc, int nclip, int T, int pad, float* conv_out) {
+    const int P = T + 2 * pad - 4;
+    const long NF = (long)nclip * P;
+    if (NF * 88 * 158 >= (1L << 31)) JG_FAIL(h, JG_ERR_ARG, "fp32 conv stack: too many positions in one pass (lower jg_set_chunk)");
+    const ConvGeom g1 = geom(FH, FW, 16, 7, 7, 3, 3, 0, 0);
+    const ConvGeom g2 = geom(43, 78, 64, 5, 5, 2, 2, 0, 0, true);       // (tap order as packed: make_conv(..., reorder = true))
+    const ConvGeom g3 = geom(20, 37, 128, 3, 3, 2, 2, 1, 1, true);
+    const ConvGeom g4 = geom(10, 19, 256, 3, 3, 1, 2, 1, 1, true);
+    const ConvGeom g5 = geom(10, 10, 256, 3, 3, 1, 1, 1, 1, true);
+    float *S, *o1, *p1, *o2, *o3, *o4, *o5, *p5;
+    RET(wsalloc(h, (size_t)NF * FH * FW * 16, &S));
+    RET(wsalloc(h, (size_t)NF * 88 * 158 * 64, &o1));
+    RET(wsalloc(h, (size_t)NF * 43 * 78 * 64, &p1));
+    RET(wsalloc(h, (size_t)NF * 20 * 37 * 128, &o2));
+    RET(wsalloc(h, (size_t)NF * 10 * 19 * 256, &o3));
+    RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o4));
+    RET(wsalloc(h, (size_t)NF * 10 * 10 * 256, &o5));
+    RET(wsalloc(h, (size_t)NF * 4 * 4 * 256, &p5));
+    RET(timed(h, JG_ST_STACK, [&] { return launch_stack_frames32(src, src_u8, sb, st, sh, sw, sc, nclip, T, pad, FH, FW, S, h->stream); }));
+    Epi32 e;
+    e.act = 1;
+    RET(gemm32(h, JG_ST_CONV1, S, 0, (int)(NF * 88 * 158), h->c1, o1, e, &g1));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2_32(o1, p1, (int)NF, 88, 158, 64, h->stream); }));
+    RET(gemm32(h, JG_ST_CONV, p1, 0, (int)(NF * 20 * 37), h->c2, o2, e, &g2));
+    RET(gemm32(h, JG_ST_CONV, o2, 0, (int)(NF * 10 * 19), h->c3, o3, e, &g3));
+    RET(gemm32(h, JG_ST_CONV, o3, 0, (int)(NF * 10 * 10), h->c4, o4, e, &g4));
+    RET(gemm32(h, JG_ST_CONV, o4, 0, (int)(NF * 10 * 10), h->c5, o5, e, &g5));
+    RET(timed(h, JG_ST_POOL, [&] { return launch_maxpool3x3s2_32(o5, p5, (int)NF, 10, 10, 256, h->stream); }));
+    return gemm32(h, JG_ST_CONV, p5, 4096, (int)NF, h->fc6, conv_out, e);
+}
+
+// post-norm transformer (gestsync.py:19-21) in place on x32, M = nseq * S tokens
+int gs_transformer32(jg_handle* h, float* x32, int nseq, int S) {
+    const int M = nseq * S;
+    float *qkv, *att, *hid, *t;
+    RET(wsalloc(h, (size_t)M * 1536, &qkv));
+    RET(wsalloc(h, (size_t)M * 512, &att));
+    RET(wsalloc(h, (size_t)M * 2048, &hid));
+    RET(wsalloc(h, (size_t)M * 512, &t));
+    Epi32 r; r.res = x32; r.ldr = 512;
+    Epi32 f; f.act = 1;
+    for (int l = 0; l < 6; ++l) {
+        const EncLayer& L = h->gs_layers[l];
+        RET(gemm32(h, JG_ST_GEMM, x32, 512, M, L.qkv, qkv));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention32(qkv, nullptr, nseq, S, 8, 64, att, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, att, 512, M, L.out, t, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t, L.n1.w, L.n1.b, M, 512, LN_STD, 0, x32, nullptr, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, x32, 512, M, L.ff1, hid, f));
+        RET(gemm32(h, JG_ST_GEMM, hid, 2048, M, L.ff2, t, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t, L.n2.w, L.n2.b, M, 512, LN_STD, 0, x32, nullptr, h->stream); }));
+    }
+    return JG_OK;
+}
+
+// windows + PE + transformer + ff_vid + mean(-1) of the clip path: conv (nb*P, 512) fp32 -> out_feats (nb*T, 1024)
+int gs_clip_tail32(jg_handle* h, const float* conv, int nb, int P, int T, int shift, float* out_feats) {
+    const int S = 21, nseq = nb * T, M = nseq * S;
+    float *x32, *hid, *full;
+    RET(wsalloc(h, (size_t)M * 512, &x32));
+    RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, P, T, S, 512, shift, 0, x32, nullptr, h->stream); }));
+    RET(gs_transformer32(h, x32, nseq, S));
+    RET(wsalloc(h, (size_t)M * 512, &hid));
+    RET(wsalloc(h, (size_t)M * 1024, &full));
+    Epi32 f; f.act = 1;
+    RET(gemm32(h, JG_ST_GEMM, x32, 512, M, h->ff0, hid, f));
+    RET(gemm32(h, JG_ST_GEMM, hid, 512, M, h->ff2, full));
+    return timed(h, JG_ST_MISC, [&] { return launch_group_mean32(full, nseq, S, 1024, out_feats, h->stream); });
+}
+
+// pre-norm encoder (modules.py:11-59) in place on x32; the final norm's output goes to n32
+int annotated_encoder32(jg_handle* h, const EncLayer* layers, int nl, const LNp& fin, float* x32, float* n32, const float* mask, int B, int S, int D, int Dff) {
+    const int M = B * S, H = 8, dk = D / H;
+    float *qkv, *att, *hid;
+    RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
+    RET(wsalloc(h, (size_t)M * D, &att));
+    RET(wsalloc(h, (size_t)M * Dff, &hid));
+    Epi32 r; r.res = x32; r.ldr = D;
+    Epi32 f; f.act = 1;
+    for (int l = 0; l < nl; ++l) {
+        const EncLayer& L = layers[l];
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, n32, D, M, L.qkv, qkv));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention32(qkv, mask, B, S, H, dk, att, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, att, D, M, L.out, x32, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, n32, D, M, L.ff1, hid, f));
+        RET(gemm32(h, JG_ST_GEMM, hid, Dff, M, L.ff2, x32, r));
+    }
+    return timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); });
+}
+
+int jegal_gestures_impl32(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
+    const int M = B * T;
+    float *t32, *t2, *x32, *n32, *g32, *a32;
+    RET(wsalloc(h, (size_t)M * 512, &t32));
+    RET(wsalloc(h, (size_t)M * 512, &t2));
+    RET(wsalloc(h, (size_t)M * 512, &x32));
+    RET(wsalloc(h, (size_t)M * 512, &n32));
+    RET(gemm32(h, JG_ST_GEMM, feats, 1024, M, h->ip0, t32));
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, t2, nullptr, h->stream); }));
+    Epi32 p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T;
+    RET(gemm32(h, JG_ST_GEMM, t2, 512, M, h->ip3, x32, p));
+    RET(annotated_encoder32(h, h->rgb_layers, 6, h->rgb_norm, x32, n32, mask, B, T, 512, 2048));
+    if (!align) return gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, out);
+    RET(wsalloc(h, (size_t)M * 512, &g32));
+    RET(wsalloc(h, (size_t)M * 512, &a32));
+    RET(gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, g32));
+    Epi32 f; f.act = 1;
+    RET(gemm32(h, JG_ST_GEMM, g32, 512, M, h->al_g0, a32, f));
+    return gemm32(h, JG_ST_GEMM, a32, 512, M, h->al_g2, out);
+}
+
+int jegal_audio_impl32(jg_handle* h, const float* mel, int B, int Tm, const int32_t* valid_host, float* out) {
+    const int F = 80;
+    const ConvGeom g0 = geom(Tm, F, 1, 5, 5, 1, 1, 2, 2);
+    const ConvGeom g3 = geom(Tm, F, 32, 3, 3, 2, 2, 1, 1);
+    const ConvGeom g6 = geom(g3.OH, g3.OW, 64, 3, 3, 2, 2, 1, 1);
+    const ConvGeom g9 = geom(g6.OH, g6.OW, 128, 3, 3, 1, 3, 1, 1);
+    const ConvGeom g12 = geom(g9.OH, g9.OW, 256, 3, 3, 1, 3, 1, 1);
+    const ConvGeom g15 = geom(g12.OH, g12.OW, 256, 1, 1, 1, 3, 0, 0);
+    if (g15.OW != 1) JG_FAIL(h, JG_ERR_ARG, "audio CNN must reduce 80 mel bands to 1");
+    int* valid = nullptr;
+    if (valid_host) {
+        bool ragged = false;
+        for (int b = 0; b < B; ++b) {
+            if (valid_host[b] < 4 || valid_host[b] > Tm) JG_FAIL(h, JG_ERR_ARG, "valid_tm[%d] = %d outside 4..Tm = %d", b, valid_host[b], Tm);
+            ragged |= valid_host[b] != Tm;
+        }
+        if (ragged) {
+            std::vector<int32_t>& hv = h->audio_valid[h->audio_valid_next++ & 3];
+            hv.assign(valid_host, valid_host + B);
+            RET(wsalloc(h, (size_t)B, &valid));
+            HIPCHK(h, hipMemcpyAsync(valid, hv.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    float *m0, *c0, *c3, *c6, *c9, *c12, *c15;
+    RET(wsalloc(h, (size_t)B * Tm * F, &m0));
+    RET(wsalloc(h, (size_t)B * Tm * F * 32, &c0));
+    RET(wsalloc(h, (size_t)B * g3.OH * g3.OW * 64, &c3));
+    RET(wsalloc(h, (size_t)B * g6.OH * g6.OW * 128, &c6));
+    RET(wsalloc(h, (size_t)B * g9.OH * g9.OW * 256, &c9));
+    RET(wsalloc(h, (size_t)B * g12.OH * g12.OW * 256, &c12));
+    RET(wsalloc(h, (size_t)B * g15.OH * 256, &c15));
+    // every layer's rows beyond a clip's own extent are zero: the padding the clip would see alone (jegal_audio_impl)
+    auto tail = [&](float* x, int halvings, int H, long row_elems) -> int {
+        if (!valid) return JG_OK;
+        return timed(h, JG_ST_MISC, [&] { return launch_zero_tail32(x, valid, halvings, B, H, row_elems, h->stream); });
+    };
+    const float* mel_in = mel;
+    if (valid) {
+        HIPCHK(h, hipMemcpyAsync(m0, mel, (size_t)B * Tm * F * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        RET(tail(m0, 0, Tm, F));
+        mel_in = m0;
+    }
+    Epi32 e; e.act = 1;
+    RET(gemm32(h, JG_ST_CONV, mel_in, 0, B * Tm * F, h->a0, c0, e, &g0));
+    RET(tail(c0, 0, Tm, (long)F * 32));
+    RET(gemm32(h, JG_ST_CONV, c0, 0, B * g3.OH * g3.OW, h->a3, c3, e, &g3));
+    RET(tail(c3, 1, g3.OH, (long)g3.OW * 64));
+    RET(gemm32(h, JG_ST_CONV, c3, 0, B * g6.OH * g6.OW, h->a6, c6, e, &g6));
+    RET(tail(c6, 2, g6.OH, (long)g6.OW * 128));
+    RET(gemm32(h, JG_ST_CONV, c6, 0, B * g9.OH * g9.OW, h->a9, c9, e, &g9));
+    RET(tail(c9, 2, g9.OH, (long)g9.OW * 256));
+    RET(gemm32(h, JG_ST_CONV, c9, 0, B * g12.OH * g12.OW, h->a12, c12, e, &g12));
+    RET(gemm32(h, JG_ST_CONV, c12, 0, B * g15.OH, h->a15, c15, Epi32(), &g15));
+    return gemm32(h, JG_ST_GEMM, c15, 256, B * g15.OH, h->op_audio, out);
+}
+
+int jegal_text_impl32(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
+    const int M = B * L;
+    float *x32, *n32;
+    RET(wsalloc(h, (size_t)M * 768, &x32));
+    RET(wsalloc(h, (size_t)M * 768, &n32));
+    HIPCHK(h, hipMemcpyAsync(x32, states, (size_t)M * 768 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    RET(annotated_encoder32(h, h->text_layers, 3, h->text_norm, x32, n32, mask, B, L, 768, 3072));
+    return gemm32(h, JG_ST_GEMM, n32, 768, M, h->op_text, out);
+}
+
+int fuse_content_impl32(jg_handle* h, const float* fused, int rows, float* out) {
+    float *a32, *b32;
+    RET(wsalloc(h, (size_t)rows * 512, &a32));
+    RET(wsalloc(h, (size_t)rows * 512, &b32));
+    Epi32 r; r.act = 1;
+    RET(gemm32(h, JG_ST_GEMM, fused, 512, rows, h->fu0, a32, r));
+    RET(gemm32(h, JG_ST_GEMM, a32, 512, rows, h->fu2, b32));
+    RET(gemm32(h, JG_ST_GEMM, b32, 512, rows, h->al_c0, a32, r));
+    return gemm32(h, JG_ST_GEMM, a32, 512, rows, h->al_c2, out);
+}
+
+// XLMRobertaModel.forward (explicit LayerNorms, un-folded matrices: finalize_xlmr packs them that way when audit weights are kept)
+int xlmr_encode_impl32(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
+    if (h->xl_folded) JG_FAIL(h, JG_ERR_STATE, "the XLM-RoBERTa weights were packed for the implicit-LayerNorm pass: finalize them with audit weights for the fp32 path");
+    constexpr int D = 768, DFF = 3072, H = 12;
+    const int M = B * L;
+    float *x32, *t32, *qkv, *att, *hid, *mk = nullptr;
+    RET(wsalloc(h, (size_t)M * D, &x32));
+    RET(wsalloc(h, (size_t)M * D, &t32));
+    RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
+    RET(wsalloc(h, (size_t)M * D, &att));
+    RET(wsalloc(h, (size_t)M * DFF, &hid));
+    if (amask) {
+        RET(wsalloc(h, (size_t)M, &mk));
+        RET(timed(h, JG_ST_MISC, [&] { return launch_mask_i32_f32(amask, mk, M, h->stream); }));
+    }
+    RET(timed(h, JG_ST_MISC, [&] { return launch_xlmr_embed(ids, B, L, D, 1, h->xl_vocab, h->xl_maxpos, h->xl_word, h->xl_pos, h->xl_type, t32, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->xl_emb_ln.w, h->xl_emb_ln.b, M, D, LN_STD, 0, x32, nullptr, h->stream); }));
+    Epi32 r; r.res = x32; r.ldr = D;
+    Epi32 f; f.act = 2;
+    for (int l = 0; l < h->xl_layers_n; ++l) {
+        const EncLayer& Ly = h->xl_layers[l];
+        const bool last = l + 1 == h->xl_layers_n;
+        RET(gemm32(h, JG_ST_GEMM, x32, D, M, Ly.qkv, qkv));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention32(qkv, mk, B, L, H, 64, att, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, att, D, M, Ly.out, t32, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n1.w, Ly.n1.b, M, D, LN_STD, 0, x32, nullptr, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, x32, D, M, Ly.ff1, hid, f));
+        RET(gemm32(h, JG_ST_GEMM, hid, DFF, M, Ly.ff2, t32, r));
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, Ly.n2.w, Ly.n2.b, M, D, LN_STD, 0, last ? out : x32, nullptr, h->stream); }));
+    }
+    return JG_OK;
+}
+
 // valid_host (optional, host [B]): clip b's first valid_host[b] frames are its own, the rest of its T frames is batch padding (copies of its
 // last frame, jg_gestsync_clip_ragged): only the run-time corrected mode looks at it -- a clip's statistics come from its own rows
 int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T, float* out_feats, const int32_t* valid_host = nullptr) {
@@ -871,8 +1146,12 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
     const int P = T + 2 * PAD - 4, S = 21;
     const size_t esz = dtype == JG_U8 ? 1 : 4;
     const long sw = 3, sh = (long)FW * 3, st = (long)FH * FW * 3, sb = (long)T * st;
-    for (int b0 = 0; b0 < B; b0 += h->chunk) {
-        const int nb = std::min(h->chunk, B - b0);
+    // fp32 audit stages (audit_mask): the conv stack and / or the transformer + ff_vid of this call run on the fp32 kernels; a pass of the
+    // fp32 conv stack holds 2.1 GB per 150-frame clip, so its passes are two clips
+    const int am = audit_mask(h);
+    const int chunk = (am & AUD_CONV) ? std::min(h->chunk, 2) : h->chunk;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
         h->ws.reset();
         if (h->ws_poison)                       // test aid: whatever a kernel reads without having written it is NaN
             for (auto& c : h->ws.chunks) HIPCHK(h, hipMemsetAsync(c.p, 0xff, c.cap, h->stream));
@@ -880,8 +1159,14 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         RET(wsalloc(h, (size_t)nb * P * 512, &conv));
         const char* src = reinterpret_cast<const char*>(frames) + (size_t)b0 * sb * esz;
         const int nseq = nb * T, M = nseq * S;
+        if (am & AUD_GS) {
+            if (am & AUD_CONV) RET(gs_conv_stack32(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
+            else RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
+            RET(gs_clip_tail32(h, conv, nb, P, T, 12 - PAD, out_feats + (size_t)b0 * T * 1024));
+            continue;
+        }
         float* x32; f16 *x16, *hid, *mean16, *conv16 = nullptr;
-        const bool tiled = gs_fused_plan(h, M);
+        const bool tiled = gs_fused_plan(h, M, T * S);
         int* rc_valid = nullptr;
         if (valid_host && tiled && h->precision == JG_PREC_FP16_RC) {
             std::vector<int32_t>& hv = h->clip_valid[h->clip_valid_next++ & 7];      // stays alive for seven more parts: the copy is stream-ordered
@@ -893,7 +1178,12 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         // layer-0 qkv from the distinct conv positions: worth it when the windows overlap (T > 1) and the MFMA attention runs
         const bool lin0 = tiled && h->qkv0_linear && h->opts.attn_mfma && T > 1;
         if (lin0) RET(wsalloc(h, (size_t)nb * P * 512, &conv16));
-        RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv, conv16));
+        if (am & AUD_CONV) {
+            RET(gs_conv_stack32(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv));
+            if (conv16) RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, (const float*)conv, conv16, (long)nb * P * 512, h->stream); }));
+        } else {
+            RET(gs_conv_stack(h, src, dtype == JG_U8, sb, st, sh, sw, 1, nb, T, PAD, conv, conv16));
+        }
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, P, T, S, 512, 12 - PAD, tiled ? (h->stream8 ? 1 : 2) : 0, x32, x16, h->stream); }));
@@ -916,18 +1206,33 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
     if (N <= 0) JG_FAIL(h, JG_ERR_ARG, "N must be positive");
     const int S = 21;
     const long sw = 1, sh = FW, st = (long)FH * FW, sc = 25 * st, sb = 3 * sc;
-    const int wchunk = std::max(1, h->chunk * 8);
+    const int am = audit_mask(h);
+    const int wchunk = (am & AUD_CONV) ? 16 : std::max(1, h->chunk * 8);      // (fp32 conv stack: 0.26 GB per window)
     for (int n0 = 0; n0 < N; n0 += wchunk) {
         const int nb = std::min(wchunk, N - n0);
         h->ws.reset();
         float* conv;
         RET(wsalloc(h, (size_t)nb * S * 512, &conv));
-        RET(gs_conv_stack(h, x + (size_t)n0 * sb, 0, sb, st, sh, sw, sc, nb, 25, 0, conv));
+        if (am & AUD_CONV) RET(gs_conv_stack32(h, x + (size_t)n0 * sb, 0, sb, st, sh, sw, sc, nb, 25, 0, conv));
+        else RET(gs_conv_stack(h, x + (size_t)n0 * sb, 0, sb, st, sh, sw, sc, nb, 25, 0, conv));
         if (out_conv)
             RET(timed(h, JG_ST_MISC, [&] { return launch_transpose_tokens(conv, nb, S, 512, out_conv + (size_t)n0 * 512 * S, h->stream); }));
         const int M = nb * S;
+        if (am & AUD_GS) {
+            float *x32a, *hida, *fulla;
+            RET(wsalloc(h, (size_t)M * 512, &x32a));
+            RET(timed(h, JG_ST_MISC, [&] { return launch_window_gather(conv, h->gs_pe, nb, S, 1, S, 512, 0, 0, x32a, nullptr, h->stream); }));
+            RET(gs_transformer32(h, x32a, nb, S));
+            RET(wsalloc(h, (size_t)M * 512, &hida));
+            RET(wsalloc(h, (size_t)M * 1024, &fulla));
+            Epi32 fa; fa.act = 1;
+            RET(gemm32(h, JG_ST_GEMM, x32a, 512, M, h->ff0, hida, fa));
+            RET(gemm32(h, JG_ST_GEMM, hida, 512, M, h->ff2, fulla));
+            RET(timed(h, JG_ST_MISC, [&] { return launch_transpose_tokens(fulla, nb, S, 1024, out + (size_t)n0 * 1024 * S, h->stream); }));
+            continue;
+        }
         float *x32, *full; f16 *x16, *hid;
-        const bool tiled = gs_fused_plan(h, M);
+        const bool tiled = gs_fused_plan(h, M, 0);
         RET(wsalloc(h, pad128(M) * 512, &x32));
         RET(wsalloc(h, pad128(M) * 512, &x16));
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_window_gather, conv, h->gs_pe, nb, S, 1, S, 512, 0, tiled ? (h->stream8 ? 1 : 2) : 0, x32, x16, h->stream); }));
@@ -972,6 +1277,7 @@ int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& f
 int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (B <= 0 || T <= 0 || T > 500) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < T <= 500 (PE table, modules.py:136)");
+    if (audit_mask(h) & AUD_JG) return jegal_gestures_impl32(h, feats, mask, B, T, align, out);
     const int M = B * T;
     f16 *f16in, *t16, *n16, *g16, *a16;
     float *t32, *x32;
@@ -1143,6 +1449,7 @@ int audio_len(int Tm) {
 int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, const int32_t* valid_host, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (B <= 0 || Tm < 4) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and Tm >= 4");
+    if (audit_mask(h) & AUD_CONTENT) return jegal_audio_impl32(h, mel, B, Tm, valid_host, out);
     const int F = 80;
     const ConvGeom g3 = geom(Tm, F, 32, 3, 3, 2, 2, 1, 1);
     const ConvGeom g6 = geom(g3.OH, g3.OW, 64, 3, 3, 2, 2, 1, 1);
@@ -1195,6 +1502,7 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, const int32_
 int jegal_text_impl(jg_handle* h, const float* states, const float* mask, int B, int L, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (B <= 0 || L <= 0) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and L > 0");
+    if (audit_mask(h) & AUD_CONTENT) return jegal_text_impl32(h, states, mask, B, L, out);
     const int M = B * L;
     float* x32; f16* n16;
     RET(wsalloc(h, (size_t)M * 768, &x32));
@@ -1231,7 +1539,9 @@ int finalize_xlmr(jg_handle* h) {
     // Implicit LayerNorm (xlmr_encode_folded): the Linear BEHIND a LayerNorm(gamma, beta) is packed as W diag(gamma) with bias
     // b + W beta (fold_consumer), the Linear whose output is ADDED to that LayerNorm's output takes beta into its bias (the
     // gamma (x - mean) rstd part is recomputed from the un-normalised stream in its epilogue).
-    const bool fold = h->xl_fold_opt && h->opts.gemm_glds;      // the implicit-LayerNorm epilogues exist in the LDS-DMA kernel only
+    // (the implicit-LayerNorm epilogues exist in the LDS-DMA kernel only; the fp32 audit path runs the explicit LayerNorms on the
+    // un-folded matrices, so audit weights switch the folding off)
+    const bool fold = h->xl_fold_opt && h->opts.gemm_glds && !h->audit_weights && h->precision != JG_PREC_FP32;
     const HostTensor *pg, *pb;          // the LayerNorm in front of the current sub-layer
     RET(need(h, "xlmr.embeddings.LayerNorm.weight", D, &pg));
     RET(need(h, "xlmr.embeddings.LayerNorm.bias", D, &pb));
@@ -1360,6 +1670,7 @@ int xlmr_encode_folded(jg_handle* h, const int32_t* ids, const int32_t* amask, i
 int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int B, int L, float* out) {
     if (!h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "XLM-RoBERTa weights not finalized (jg_finalize_weights(h, 4))");
     if (B <= 0 || L <= 0 || L > h->xl_maxpos - 2) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < L <= %d", h->xl_maxpos - 2);
+    if (audit_mask(h) & AUD_XLMR) return xlmr_encode_impl32(h, ids, amask, B, L, out);
     if (h->xl_folded && !h->opts.gemm_glds)
         JG_FAIL(h, JG_ERR_STATE, "the XLM-RoBERTa weights were packed for the implicit-LayerNorm pass, which needs the LDS-DMA GEMM: set option "
                                  "gemm_glds=0 (or xlmr_fold=0) BEFORE jg_finalize_weights(h, 4)");
@@ -1400,6 +1711,7 @@ int xlmr_encode_impl(jg_handle* h, const int32_t* ids, const int32_t* amask, int
 int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (rows <= 0) JG_FAIL(h, JG_ERR_ARG, "rows must be positive");
+    if (audit_mask(h) & AUD_CONTENT) return fuse_content_impl32(h, fused, rows, out);
     f16 *x16, *a16, *b16;
     RET(wsalloc(h, (size_t)rows * 512, &x16));
     RET(wsalloc(h, (size_t)rows * 512, &a16));
@@ -1428,7 +1740,7 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int equal_lanes = 0) 
     for (int l = 1; l <= nl; ++l) start[l] = equal_lanes ? (int)((long)B * l / nl) : (l == 1 ? (h->dual_split32 ? (B * h->dual_split32 + 16) / 32 : (B * h->dual_split + 4) / 8) : B);
     int smallest = B;
     for (int l = 0; l < nl; ++l) smallest = std::min(smallest, start[l + 1] - start[l]);
-    if (!h->dual_stream || h->calib || nl < 2 || B < 8 || (long)smallest * T < 256) return run_part(0, B);
+    if (!h->dual_stream || h->calib || nl < 2 || B < 8 || (long)smallest * T < 256 || audit_mask(h)) return run_part(0, B);
     for (int l = 0; l < nl; ++l)
         if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
     for (int e = 0; e < nl + 1; ++e)
@@ -1542,7 +1854,7 @@ int jg_set_stream(jg_handle* h, void* s) {
 
 int jg_set_precision(jg_handle* h, int mode) {
     if (!h) return JG_ERR_ARG;
-    if (mode < JG_PREC_FP16 || mode > JG_PREC_FP16_RC) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
+    if (mode < JG_PREC_FP16 || mode > JG_PREC_FP32) JG_FAIL(h, JG_ERR_ARG, "unknown precision mode %d", mode);
     if ((h->gs_ready || h->jg_ready || h->xl_ready) && mode != h->precision) JG_FAIL(h, JG_ERR_STATE, "set the precision before jg_finalize_weights");
     h->precision = mode;
     h->bf16 = mode == JG_PREC_BF16;
@@ -1567,6 +1879,17 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "audit_weights")) {
+        if (h->gs_ready || h->jg_ready || h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "set audit_weights before jg_finalize_weights");
+        h->audit_weights = value != 0;
+        return JG_OK;
+    }
+    if (!std::strcmp(name, "audit_stages")) {
+        if (value < 0 || value > 31) JG_FAIL(h, JG_ERR_ARG, "audit_stages is a mask of 5 bits");
+        if (value && !h->audit_weights && h->precision != JG_PREC_FP32) JG_FAIL(h, JG_ERR_STATE, "audit_stages needs option audit_weights=1 set before jg_finalize_weights");
+        h->audit_stages = value;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "dual_stream")) { h->dual_stream = value != 0; return JG_OK; }
     if (!std::strcmp(name, "num_cu")) {          // experiments: persistent kernels of this handle launch this many workgroups (<= the device's CUs)
         if (value < 8 || value > 1024) JG_FAIL(h, JG_ERR_ARG, "num_cu out of range");

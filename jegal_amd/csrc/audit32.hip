@@ -1,0 +1,350 @@
+// fp32 audit kernels (gfx950): see audit32.h.  Exact fp32 products on v_mfma_f32_32x32x2_f32, fp32 everywhere else.
+#include "audit32.h"
+
+namespace {
+
+__device__ __forceinline__ float act1(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution.  Block tile 128 (m) x 128 (n), 4 waves of 64 x 64 (2 x 2 MFMA blocks of 32 x 32), k-step 16 through
+// LDS stored [k][row] so the one-float MFMA fragment reads (lane -> row l & 31, k l >> 5) are conflict free; the next k-tile's
+// global loads are issued before the MFMAs of the current one.  The WEIGHT tile is the MFMA "A" operand: a lane ends up with four
+// consecutive n of one m per accumulator quad (16-byte stores).
+// VEC: every 4-aligned k-quad of a row is contiguous in memory and 16-byte aligned (plain: lda % 4 == 0; conv: C % 4 == 0).
+constexpr int G32_BM = 128, G32_BN = 128, G32_BK = 16, G32_LD = 132;
+
+template <bool CONV, bool VEC>
+__global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Args a) {
+    __shared__ float sX[G32_BK][G32_LD];
+    __shared__ float sW[G32_BK][G32_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n_tiles = (a.N + G32_BN - 1) / G32_BN;
+    const int n0 = (blockIdx.x % n_tiles) * G32_BN;
+    const int m0 = (int)(blockIdx.x / n_tiles) * G32_BM;
+    // loader: thread -> (row r = t >> 1, k half = t & 1: eight consecutive k of the 16)
+    const int r = t >> 1, kh8 = (t & 1) * 8;
+    const int mrow = m0 + r, nrow = n0 + r;
+    const bool xok = mrow < a.M, wok = nrow < a.N;
+    long xbase = 0;
+    int ih0 = 0, iw0 = 0;
+    if (CONV) {
+        const int mm = xok ? mrow : 0;
+        const int per = a.g.OH * a.g.OW;
+        const int img = mm / per, rem = mm - img * per;
+        const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+        ih0 = oh * a.g.SH - a.g.PH;
+        iw0 = ow * a.g.SW - a.g.PW;
+        xbase = (long)img * a.g.H * a.g.W * a.g.C;
+    } else {
+        xbase = (long)(xok ? mrow : 0) * a.lda;
+    }
+    const long wbase = (long)(wok ? nrow : 0) * a.ldw;
+
+    auto load_x1 = [&](int k) -> float {
+        if (!xok || k >= a.K) return 0.f;
+        if (CONV) {
+            const int ci = k & (a.g.C - 1), kp = k >> a.g.cshift;
+            int kh, kw;
+            tap_decode(a.g, kp, kh, kw);
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            if ((unsigned)ih >= (unsigned)a.g.H || (unsigned)iw >= (unsigned)a.g.W || kh >= a.g.KH) return 0.f;
+            return a.A[xbase + ((long)ih * a.g.W + iw) * a.g.C + ci];
+        }
+        return a.A[xbase + k];
+    };
+    auto load_x4 = [&](int k) -> f32x4 {
+        if (VEC) {
+            if (!xok || k >= a.K) return f32x4{0.f, 0.f, 0.f, 0.f};
+            if (CONV) {
+                const int ci = k & (a.g.C - 1), kp = k >> a.g.cshift;
+                int kh, kw;
+                tap_decode(a.g, kp, kh, kw);
+                const int ih = ih0 + kh, iw = iw0 + kw;
+                if ((unsigned)ih >= (unsigned)a.g.H || (unsigned)iw >= (unsigned)a.g.W || kh >= a.g.KH) return f32x4{0.f, 0.f, 0.f, 0.f};
+                return *reinterpret_cast<const f32x4*>(a.A + xbase + ((long)ih * a.g.W + iw) * a.g.C + ci);
+            }
+            return *reinterpret_cast<const f32x4*>(a.A + xbase + k);
+        }
+        return f32x4{load_x1(k), load_x1(k + 1), load_x1(k + 2), load_x1(k + 3)};
+    };
+    auto load_w4 = [&](int k) -> f32x4 {
+        if (!wok) return f32x4{0.f, 0.f, 0.f, 0.f};
+        if (VEC && k + 3 < a.K) return *reinterpret_cast<const f32x4*>(a.W + wbase + k);
+        f32x4 v;
+        v.x = k < a.K ? a.W[wbase + k] : 0.f;
+        v.y = k + 1 < a.K ? a.W[wbase + k + 1] : 0.f;
+        v.z = k + 2 < a.K ? a.W[wbase + k + 2] : 0.f;
+        v.w = k + 3 < a.K ? a.W[wbase + k + 3] : 0.f;
+        return v;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+    const int nk = (a.K + G32_BK - 1) / G32_BK;
+    f32x4 xr[2], wr[2];
+    xr[0] = load_x4(kh8);
+    xr[1] = load_x4(kh8 + 4);
+    wr[0] = load_w4(kh8);
+    wr[1] = load_w4(kh8 + 4);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            sX[kh8 + q * 4 + 0][r] = xr[q].x; sX[kh8 + q * 4 + 1][r] = xr[q].y; sX[kh8 + q * 4 + 2][r] = xr[q].z; sX[kh8 + q * 4 + 3][r] = xr[q].w;
+            sW[kh8 + q * 4 + 0][r] = wr[q].x; sW[kh8 + q * 4 + 1][r] = wr[q].y; sW[kh8 + q * 4 + 2][r] = wr[q].z; sW[kh8 + q * 4 + 3][r] = wr[q].w;
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k = (kt + 1) * G32_BK + kh8;
+            xr[0] = load_x4(k);
+            xr[1] = load_x4(k + 4);
+            wr[0] = load_w4(k);
+            wr[1] = load_w4(k + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < G32_BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float w0 = sW[kr][wn * 64 + (lane & 31)], w1 = sW[kr][wn * 64 + 32 + (lane & 31)];
+            const float x0 = sX[kr][wm * 64 + (lane & 31)], x1 = sX[kr][wm * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D layout: B index (m) = lane & 31, A index (n) = (x & 3) + 8 (x >> 2) + 4 (lane >> 5)
+    const bool n4ok = (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.res || (a.ldr & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+        if (m >= a.M) continue;
+        const long rr = a.res ? (long)(a.res_mod ? m % a.res_mod : m) * a.ldr : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = acc[i][j][q * 4 + e];
+                    if (n + e < a.N) {
+                        if (a.scale) y *= a.scale[n + e];
+                        if (a.bias) y += a.bias[n + e];
+                        if (a.res) y += a.res[rr + n + e];
+                    }
+                    v[e] = act1(y, a.act);
+                }
+                if (n4ok) {
+                    *reinterpret_cast<f32x4*>(a.out + (long)m * a.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < a.N) a.out[(long)m * a.ldc + n + e] = v[e];
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention, one thread per query row, keys / values through LDS in chunks of KC, online softmax (fp32).  A block holds the queries of
+// ONE (sequence, head); blockDim = min(256, S rounded up to 64).
+template <int DK>
+__global__ __launch_bounds__(256) void attention32_kernel(const float* __restrict__ qkv, const float* __restrict__ keymask, int S, int H,
+                                                          float* __restrict__ out) {
+    constexpr int KC = 32;
+    __shared__ float sK[KC][DK];
+    __shared__ float sV[KC][DK];
+    __shared__ float sM[KC];
+    const int bh = blockIdx.x, b = bh / H, hd = bh - b * H;
+    const int D = H * DK;
+    const int qi = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool live = qi < S;
+    const float scale = 1.0f / sqrtf((float)DK);
+    float q[DK], o[DK];
+    const float* qp = qkv + ((long)b * S + (live ? qi : 0)) * 3 * D + hd * DK;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) { q[d] = qp[d]; o[d] = 0.f; }
+    float mx = -INFINITY, l = 0.f;
+    for (int c0 = 0; c0 < S; c0 += KC) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KC * DK; i += blockDim.x) {
+            const int j = i / DK, d = i - j * DK;
+            const bool ok = c0 + j < S;
+            const float* kp = qkv + ((long)b * S + (ok ? c0 + j : 0)) * 3 * D + D + hd * DK + d;
+            sK[j][d] = ok ? kp[0] : 0.f;
+            sV[j][d] = ok ? kp[D] : 0.f;
+        }
+        for (int j = threadIdx.x; j < KC; j += blockDim.x) sM[j] = (c0 + j < S && keymask) ? keymask[(long)b * S + c0 + j] : 1.f;
+        __syncthreads();
+        const int nj = S - c0 < KC ? S - c0 : KC;
+        for (int j = 0; j < nj; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DK; ++d) sc = __builtin_fmaf(q[d], sK[j][d], sc);
+            sc *= scale;
+            if (sM[j] == 0.f) sc = -1e9f;                 // masked_fill(mask == 0, -1e9), modules.py:69-70
+            const float mn = fmaxf(mx, sc);
+            const float corr = expf(mx - mn), p = expf(sc - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int d = 0; d < DK; ++d) o[d] = __builtin_fmaf(p, sV[j][d], o[d] * corr);
+            mx = mn;
+        }
+    }
+    if (!live) return;
+    const float inv = 1.f / l;
+    float* op = out + ((long)b * S + qi) * D + hd * DK;
+#pragma unroll
+    for (int d = 0; d < DK; ++d) op[d] = o[d] * inv;
+}
+
+template <typename SRC>
+__global__ void stack_frames32_kernel(const SRC* __restrict__ src, long sb, long st, long sh, long sw, long sc, int B, int T, int pad, int H, int W,
+                                      float* __restrict__ dst) {
+    const int P = T + 2 * pad - 4;
+    const long total = (long)B * P * H * W;
+    constexpr bool U8 = sizeof(SRC) == 1;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int w = idx % W;
+        long r = idx / W;
+        const int h = r % H;
+        r /= H;
+        const int p = r % P;
+        const int b = r / P;
+        float v[16];
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+            int f = p + dt - pad;
+            f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+            const SRC* s = src + b * sb + f * st + h * sh + w * sw;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[dt * 3 + c] = U8 ? (float)s[c * sc] / 255.0f : (float)s[c * sc];      // IEEE division, as numpy's / 255.
+        }
+        v[15] = 0.f;
+        f32x4* d = reinterpret_cast<f32x4*>(dst + idx * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = f32x4{v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+    }
+}
+
+__global__ void maxpool32_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int OH, int OW) {
+    const int cv = C / 4;
+    const long total = (long)N * OH * OW * cv;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = idx % cv;
+        long r = idx / cv;
+        const int ow = r % OW;
+        r /= OW;
+        const int oh = r % OH;
+        const long n = r / OH;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((n * H + oh * 2 + kh) * W + ow * 2 + kw) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        *reinterpret_cast<f32x4*>(out + idx * 4) = m;
+    }
+}
+
+__global__ void group_mean32_kernel(const float* __restrict__ in, int groups, int L, int D, float* __restrict__ out) {
+    const int dv = D / 4;
+    const long total = (long)groups * dv;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int d4 = idx % dv;
+        const long g = idx / dv;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < L; ++j) acc += *reinterpret_cast<const f32x4*>(in + (g * L + j) * D + d4 * 4);
+        *reinterpret_cast<f32x4*>(out + idx * 4) = acc / (float)L;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_tail32_kernel(float* __restrict__ x, const int* __restrict__ valid, int halvings, int H, int row_vec) {
+    const int b = blockIdx.x / H, hrow = blockIdx.x - b * H;
+    int len = max(valid[b], 0);
+    for (int i = 0; i < halvings; ++i) len = len > 0 ? (len - 1) / 2 + 1 : 0;
+    if (hrow < len) return;
+    f32x4* p = reinterpret_cast<f32x4*>(x) + (long)blockIdx.x * row_vec;
+    for (int i = threadIdx.x; i < row_vec; i += 256) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+inline int grid_for(long total) { return (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4); }
+
+}  // namespace
+
+hipError_t launch_gemm32(const Gemm32Args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (a.K <= 0 || !a.A || !a.W || !a.out) return hipErrorInvalidValue;
+    const long mt = (a.M + G32_BM - 1) / G32_BM, nt = (a.N + G32_BN - 1) / G32_BN;
+    const dim3 grid((unsigned)(mt * nt)), block(256);
+    const bool walign = (a.ldw & 3) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.A & 15) == 0;
+    if (a.conv) {
+        if ((1 << a.g.cshift) != a.g.C || a.g.rowmap || a.g.const_in) return hipErrorInvalidValue;
+        if (walign && (a.g.C & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (walign && (a.lda & 3) == 0 && (a.K & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_attention32(const float* qkv, const float* keymask, int B, int S, int H, int dk, float* out, hipStream_t s) {
+    if (B <= 0 || S <= 0) return hipSuccess;
+    const int threads = S >= 256 ? 256 : (S + 63) / 64 * 64;
+    const dim3 grid((unsigned)(B * H), (unsigned)((S + threads - 1) / threads));
+    if (dk == 64) hipLaunchKernelGGL(attention32_kernel<64>, grid, dim3(threads), 0, s, qkv, keymask, S, H, out);
+    else if (dk == 96) hipLaunchKernelGGL(attention32_kernel<96>, grid, dim3(threads), 0, s, qkv, keymask, S, H, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_stack_frames32(const void* src, int src_is_u8, long sb, long st, long sh, long sw, long sc, int B, int T, int pad, int H, int W,
+                                 float* dst, hipStream_t s) {
+    const long total = (long)B * (T + 2 * pad - 4) * H * W;
+    if (total <= 0) return hipSuccess;
+    if (src_is_u8)
+        hipLaunchKernelGGL(stack_frames32_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)src, sb, st, sh, sw, sc, B, T, pad, H, W, dst);
+    else
+        hipLaunchKernelGGL(stack_frames32_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, sb, st, sh, sw, sc, B, T, pad, H, W, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_maxpool3x3s2_32(const float* in, float* out, int N, int H, int W, int C, hipStream_t s) {
+    if (C % 4) return hipErrorInvalidValue;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const long total = (long)N * OH * OW * (C / 4);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(maxpool32_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_mean32(const float* in, int groups, int L, int D, float* out, hipStream_t s) {
+    if (D % 4) return hipErrorInvalidValue;
+    const long total = (long)groups * (D / 4);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_mean32_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, groups, L, D, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_tail32(float* x, const int* valid, int halvings, int B, int H, long row_elems, hipStream_t s) {
+    if (B <= 0 || H <= 0 || !valid) return hipSuccess;
+    if (row_elems % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_tail32_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, x, valid, halvings, H, (int)(row_elems / 4));
+    return hipGetLastError();
+}

@@ -139,10 +139,8 @@ __global__ void window_gather_kernel(const float* __restrict__ conv, const float
         f32x4 v = *reinterpret_cast<const f32x4*>(conv + ((long)b * P + pp) * D + d4 * 4);
         v += *reinterpret_cast<const f32x4*>(pe + (long)j * D + d4 * 4);
         const f16x4 h = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-        {
-            *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
-            *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;
-        }
+        *reinterpret_cast<f32x4*>(x32 + idx * 4) = v;
+        if (x16) *reinterpret_cast<f16x4*>(x16 + idx * 4) = h;      // (nullptr: the fp32 audit path)
     }
 }
 

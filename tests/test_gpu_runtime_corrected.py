@@ -109,10 +109,26 @@ def test_rc_short_and_windowed_inputs(rc):
         rc.calibrate()                                   # there is nothing to calibrate in this mode
 
 
-@pytest.mark.parametrize("B,T,chunk", [(5, 13, 32), (40, 25, 64), (3, 37, 32), (2, 24, 32)])
+def test_rc_forward_vid_with_many_windows(rc):
+    """forward_vid on >= 49 windows (M >= 1024 tokens, no clip structure): the unfused hi+lo plan, not the LayerNorm-fused kernels that
+    only exist with the per-clip bias (before round 6 this call failed with hipErrorInvalidValue)."""
+    from jegal_amd.gestsync import GestSync
+    gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(52, 3, 25, 270, 480, generator=g)
+    out = GestSync(engine=rc).load_state_dict(synth.gestsync_state_dict(include_unused=False)).forward_vid(x.cuda()).cpu()
+    assert torch.isfinite(out).all()
+    pick = [0, 25, 51]
+    with torch.no_grad():
+        refw = O.gestsync_forward_vid(gsd, x[pick])
+    assert rel(out[pick], refw) < TOL
+
+
+@pytest.mark.parametrize("B,T,chunk", [(5, 13, 32), (40, 25, 64), (3, 37, 32), (2, 24, 32), (5, 12, 32), (8, 10, 32)])
 def test_rc_odd_shapes_vs_oracle(rc, B, T, chunk):
     """Rows per clip below the sampling threshold (every row is used), not a multiple of 16 or of the tile height, more than 32 clips in
-    one pass (two clip groups in the correction product), and a batch too small for the fused plan (M < 1024: hi+lo)."""
+    one pass (two clip groups in the correction product), a batch too small for the fused plan (M < 1024: hi+lo), and clips too short for
+    the per-clip bias (T <= 12, i.e. fewer than 256 rows per clip, in a batch of >= 1024 rows: ADVICE r5 -- the unfused hi+lo plan)."""
     gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
     frames = synth.synth_frames(900 + T, B, T)
     rc.set_chunk(chunk)
