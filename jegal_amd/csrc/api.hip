@@ -190,6 +190,10 @@ struct jg_handle {
     // 4 XLM-RoBERTa; JG_PREC_FP32 = all of them) -- the stage boundaries are fp32 tensors in every mode, so stages can be mixed
     bool audit_weights = false;
     int audit_stages = 0;
+    // diagnosis inside the fp16 JEGAL gesture branch (option "audit_jegal_parts", needs audit_weights): 1 input projection, 2 attention
+    // sub-layers, 4 feed-forward sub-layers, 8 final norm + output / align projections run on the fp32 kernels (the residual stream
+    // between them is fp32 in every mode)
+    int audit_jegal_parts = 0;
     int xl_lanes = 2;              // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams
 };
 
@@ -1002,6 +1006,49 @@ int annotated_encoder32(jg_handle* h, const EncLayer* layers, int nl, const LNp&
     return timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); });
 }
 
+// ONE sub-layer of a pre-norm encoder layer on the fp32 kernels, in place on the fp32 residual stream (which = 1: x += out(attn(qkv(LN1 x))),
+// 2: x += ff2(relu(ff1(LN2 x)))); scratch: M * (D + 3 D + D + Dff) floats.  (Diagnosis: annotated_encoder's `parts`.)
+int encoder_sublayers32(jg_handle* h, const EncLayer& L, int which, float* x32, float* scratch, const float* mask, int B, int S, int D, int Dff) {
+    const int M = B * S, H = 8, dk = D / H;
+    float* n32 = scratch;
+    float* qkv = n32 + (size_t)M * D;
+    float* att = qkv + (size_t)M * 3 * D;
+    float* hid = att + (size_t)M * D;
+    Epi32 r; r.res = x32; r.ldr = D;
+    if (which == 1) {
+        RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); }));
+        RET(gemm32(h, JG_ST_GEMM, n32, D, M, L.qkv, qkv));
+        RET(timed(h, JG_ST_ATTN, [&] { return launch_attention32(qkv, mask, B, S, H, dk, att, h->stream); }));
+        return gemm32(h, JG_ST_GEMM, att, D, M, L.out, x32, r);
+    }
+    Epi32 f; f.act = 1;
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); }));
+    RET(gemm32(h, JG_ST_GEMM, n32, D, M, L.ff1, hid, f));
+    return gemm32(h, JG_ST_GEMM, hid, Dff, M, L.ff2, x32, r);
+}
+
+// proj_ip_rgb + positional rows (jegal.py:25-28,84-85) on the fp32 kernels: feats (M,1024) -> x32 (M,512); t32: (M,512) scratch
+int jegal_input32(jg_handle* h, const float* feats, int M, int T, float* t32, float* x32) {
+    float* t2;
+    RET(wsalloc(h, (size_t)M * 512, &t2));
+    RET(gemm32(h, JG_ST_GEMM, feats, 1024, M, h->ip0, t32));
+    RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, t2, nullptr, h->stream); }));
+    Epi32 p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T;
+    return gemm32(h, JG_ST_GEMM, t2, 512, M, h->ip3, x32, p);
+}
+
+// proj_op_rgb (+ proj_op_align_gesture) on the fp32 kernels from the final norm's fp32 output
+int jegal_tail32(jg_handle* h, const float* n32, int M, int align, float* out) {
+    if (!align) return gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, out);
+    float *g32, *a32;
+    RET(wsalloc(h, (size_t)M * 512, &g32));
+    RET(wsalloc(h, (size_t)M * 512, &a32));
+    RET(gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, g32));
+    Epi32 f; f.act = 1;
+    RET(gemm32(h, JG_ST_GEMM, g32, 512, M, h->al_g0, a32, f));
+    return gemm32(h, JG_ST_GEMM, a32, 512, M, h->al_g2, out);
+}
+
 int jegal_gestures_impl32(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
     const int M = B * T;
     float *t32, *t2, *x32, *n32, *g32, *a32;
@@ -1250,27 +1297,39 @@ int gestsync_windows_impl(jg_handle* h, const float* x, int N, float* out, float
 
 // ------------------------------------------------------------------------------------ JEGAL
 // pre-norm encoder (modules.py:11-59) in place on x32; returns final-norm output in n16
+// parts (diagnosis, option audit_jegal_parts): bit 1 = the attention sub-layers, bit 2 = the feed-forward sub-layers run on the fp32 audit
+// kernels (encoder_sublayers32, with the audit path above)
 int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& fin, float* x32, f16* n16,
-                      const float* mask, int B, int S, int D, int Dff) {
+                      const float* mask, int B, int S, int D, int Dff, int parts = 0, float* n32_out = nullptr) {
     const int M = B * S, H = 8, dk = D / H;
     f16 *qkv, *att, *hid;
+    float* scr32 = nullptr;
     RET(wsalloc(h, (size_t)M * 3 * D, &qkv));
     RET(wsalloc(h, (size_t)M * D, &att));
     RET(wsalloc(h, (size_t)M * Dff, &hid));
+    if (parts & 6) RET(wsalloc(h, (size_t)M * (D + 3 * D + D + Dff), &scr32));
     for (int l = 0; l < nl; ++l) {
         const EncLayer& L = layers[l];
-        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
-        Epi e; e.out16 = qkv;
-        RET(gemm(h, JG_ST_GEMM, n16, D, M, L.qkv, e));
-        RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mask, B, S, H, dk, att, h->opts, h->stream); }));
         Epi r; r.res = x32; r.ldr = D; r.out32 = x32;
-        RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
-        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
-        Epi f; f.relu = 1; f.out16 = hid;
-        RET(gemm(h, JG_ST_GEMM, n16, D, M, L.ff1, f));
-        RET(gemm(h, JG_ST_GEMM, hid, Dff, M, L.ff2, r));
+        if (parts & 2) {
+            RET(encoder_sublayers32(h, L, 1, x32, scr32, mask, B, S, D, Dff));
+        } else {
+            RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n1.w, L.n1.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+            Epi e; e.out16 = qkv;
+            RET(gemm(h, JG_ST_GEMM, n16, D, M, L.qkv, e));
+            RET(timed(h, JG_ST_ATTN, [&] { return LAUNCH(h, launch_attention, qkv, mask, B, S, H, dk, att, h->opts, h->stream); }));
+            RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
+        }
+        if (parts & 4) {
+            RET(encoder_sublayers32(h, L, 2, x32, scr32, mask, B, S, D, Dff));
+        } else {
+            RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+            Epi f; f.relu = 1; f.out16 = hid;
+            RET(gemm(h, JG_ST_GEMM, n16, D, M, L.ff1, f));
+            RET(gemm(h, JG_ST_GEMM, hid, Dff, M, L.ff2, r));
+        }
     }
-    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
+    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, fin.w, fin.b, M, D, LN_ANNOTATED, 0, n32_out, n16, h->stream); }));
     return JG_OK;
 }
 
@@ -1279,20 +1338,27 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     if (B <= 0 || T <= 0 || T > 500) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < T <= 500 (PE table, modules.py:136)");
     if (audit_mask(h) & AUD_JG) return jegal_gestures_impl32(h, feats, mask, B, T, align, out);
     const int M = B * T;
+    const int parts = h->audit_jegal_parts;
     f16 *f16in, *t16, *n16, *g16, *a16;
-    float *t32, *x32;
+    float *t32, *x32, *n32 = nullptr;
     RET(wsalloc(h, (size_t)M * 1024, &f16in));
     RET(wsalloc(h, (size_t)M * 512, &t32));
     RET(wsalloc(h, (size_t)M * 512, &t16));
     RET(wsalloc(h, (size_t)M * 512, &x32));
     RET(wsalloc(h, (size_t)M * 512, &n16));
-    RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, feats, f16in, (long)M * 1024, h->stream); }));
-    Epi e; e.out32 = t32;
-    RET(gemm(h, JG_ST_GEMM, f16in, 1024, M, h->ip0, e));
-    RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, nullptr, t16, h->stream); }));
-    Epi p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T; p.out32 = x32;
-    RET(gemm(h, JG_ST_GEMM, t16, 512, M, h->ip3, p));
-    RET(annotated_encoder(h, h->rgb_layers, 6, h->rgb_norm, x32, n16, mask, B, T, 512, 2048));
+    if (parts & 8) RET(wsalloc(h, (size_t)M * 512, &n32));
+    if (parts & 1) {
+        RET(jegal_input32(h, feats, M, T, t32, x32));
+    } else {
+        RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, feats, f16in, (long)M * 1024, h->stream); }));
+        Epi e; e.out32 = t32;
+        RET(gemm(h, JG_ST_GEMM, f16in, 1024, M, h->ip0, e));
+        RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, nullptr, t16, h->stream); }));
+        Epi p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T; p.out32 = x32;
+        RET(gemm(h, JG_ST_GEMM, t16, 512, M, h->ip3, p));
+    }
+    RET(annotated_encoder(h, h->rgb_layers, 6, h->rgb_norm, x32, n16, mask, B, T, 512, 2048, parts, n32));
+    if (parts & 8) return jegal_tail32(h, n32, M, align, out);
     if (!align) {
         Epi o; o.out32 = out;
         return gemm(h, JG_ST_GEMM, n16, 512, M, h->op_rgb, o);
@@ -1882,6 +1948,12 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "audit_weights")) {
         if (h->gs_ready || h->jg_ready || h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "set audit_weights before jg_finalize_weights");
         h->audit_weights = value != 0;
+        return JG_OK;
+    }
+    if (!std::strcmp(name, "audit_jegal_parts")) {
+        if (value < 0 || value > 15) JG_FAIL(h, JG_ERR_ARG, "audit_jegal_parts is a mask of 4 bits");
+        if (value && !h->audit_weights && h->precision != JG_PREC_FP32) JG_FAIL(h, JG_ERR_STATE, "audit_jegal_parts needs option audit_weights=1 set before jg_finalize_weights");
+        h->audit_jegal_parts = value;
         return JG_OK;
     }
     if (!std::strcmp(name, "audit_stages")) {

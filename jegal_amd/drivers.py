@@ -40,9 +40,10 @@ def load_checkpoint(path, kind):
 
 
 def _add_precision_args(p):
-    p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3, 5],
+    p.add_argument("--precision", type=int, default=None, choices=[0, 1, 2, 3, 5, 6],
                    help="engine precision mode (include/jegal_hip.h); default: 5 (run-time corrected fp16: per-clip, calibration-free), "
-                        "or 3 (bias-corrected fp16, ~3 %% faster) when --calibrate_frames is given")
+                        "or 3 (bias-corrected fp16, ~3 %% faster) when --calibrate_frames is given; 6 = the fp32 audit mode (exact-fp32 "
+                        "MFMAs, fp32 activations: the reference's CPU arithmetic, ~50x slower)")
     p.add_argument("--calibrate_frames", default=None,
                    help=".npy of masked uint8 crops (B,T,270,480,3) or (T,270,480,3): re-run the precision-mode-3 calibration on them")
 
@@ -488,6 +489,10 @@ def cmd_inference_embs(argv):
     p.add_argument("--xlmr_checkpoint", default=None)
     p.add_argument("--tokenizer", default=None)
     _add_precision_args(p)
+    p.add_argument("--audit", action="store_true",
+                   help="run the clip a second time in the fp32 audit mode (precision 6, a second engine with the same checkpoints) and print "
+                        "the rel-L2 / max-abs of the embeddings above against it: the 1e-3 contract checked on YOUR clip and checkpoint, where "
+                        "no CPU reference is at hand (a network that amplifies operand rounding beyond it shows up here; DESIGN.md section 3)")
     args = p.parse_args(argv)
     mod = args.modalities
     for m, arg in (("v", "video_path"), ("a", "audio_path")):                # inference_embs.py:650-664
@@ -503,6 +508,53 @@ def cmd_inference_embs(argv):
                             precision=args.precision, calibrate_frames=args.calibrate_frames)
     eng, gs, jg = _models(ns, need_gestsync="v" in mod, need_jegal=True)
     os.makedirs(args.res_dir, exist_ok=True)
+    gesture, content, fname, wbs, text_strs = _inference_embs_clip(args, mod, eng, gs, jg, verbose=True)
+    if args.audit:
+        rep = audit_against_fp32(args, mod, gesture, content)
+        print("Audit (fp32 engine, same clip and checkpoints): " + "; ".join(
+            f"{k} rel-L2 {v['rel_l2']:.2e} max-abs {v['max_abs']:.2e}" for k, v in rep.items()))
+        bad = [k for k, v in rep.items() if not (v["rel_l2"] < 1e-3 and v["max_abs"] < 1e-3)]
+        if bad:
+            print("WARNING: " + ", ".join(bad) + " exceed(s) the 1e-3 contract in precision mode {}: this checkpoint amplifies fp16 operand "
+                  "rounding (DESIGN.md section 3, `sharp` family); use --precision 6 for the embeddings themselves.".format(eng.precision))
+    print("------------------------------------------------")
+    feat = {"gesture_emb": gesture, "content_emb": content,
+            "info": {"fname": fname, "word_boundaries": None if wbs is None else wbs[0], "text": None if text_strs is None else text_strs[0]}}
+    output_fname = os.path.join(args.res_dir, fname + ".pkl")
+    with open(output_fname, "wb") as f:
+        pickle.dump(feat, f)
+    print("Saved the embeddings: ", output_fname)
+    return 0
+
+
+def audit_against_fp32(args, mod, gesture, content):
+    """--audit: the same clip through a second engine in JG_PREC_FP32 (exact-fp32 MFMAs, fp32 activations end to end: the arithmetic of the
+    reference's CPU path, inference_embs.py:497) with the same checkpoints -> {"gesture" | "content": {"rel_l2", "max_abs"}} of the
+    embeddings passed in against it."""
+    from ._lib import Engine, PREC_FP32
+    from .gestsync import GestSync
+    from .jegal import JEGAL
+    e32 = Engine(torch.cuda.current_device(), precision=PREC_FP32)
+    try:
+        gs32 = GestSync(engine=e32).load_state_dict(load_checkpoint(args.checkpoint_path_gestsync, "gestsync")) if "v" in mod else None
+        jg32 = JEGAL(engine=e32).load_state_dict(load_checkpoint(args.checkpoint_path_jegal, "jegal"))
+        g32, c32, _, _, _ = _inference_embs_clip(args, mod, e32, gs32, jg32, verbose=False)
+    finally:
+        e32.close()
+    rep = {}
+    for name, a, b in (("gesture", gesture, g32), ("content", content, c32)):
+        if a is not None:
+            a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            rep[name] = {"rel_l2": float(np.linalg.norm(a64 - b64) / max(np.linalg.norm(b64), 1e-30)), "max_abs": float(np.abs(a64 - b64).max())}
+    return rep
+
+
+def _inference_embs_clip(args, mod, eng, gs, jg, verbose=True):
+    """frames / wav / text of one clip -> (gesture (T,512) | None, content (W,512) | None, fname, word boundaries, text): extract_embs of
+    inference_embs.py:526-646 on `eng`."""
+    from . import audio as jaudio
+    from . import extract
+    say = print if verbose else (lambda *a, **k: None)
     vis = mask = text = audio = am = wbs = None
     fname = None
     text_strs = None
@@ -517,21 +569,21 @@ def cmd_inference_embs(argv):
             if tuple(frames.shape[1:3]) != (270, 480):
                 raise ValueError("frames that are not 270x480 need --mask_y (source-resolution path)")
             crops = torch.from_numpy(frames).to(eng.device)
-        print("Input masked frames: ", tuple(crops.shape))
-        print("Extracting pre-trained GestSync features...")
+        say("Input masked frames: ", tuple(crops.shape))
+        say("Extracting pre-trained GestSync features...")
         vis = gs.extract_clip_feats(crops)                                   # (1,T,1024): get_gestsync_feats (:476-522)
         mask = torch.ones(vis.shape[:2], device=vis.device)
         fname = os.path.basename(args.video_path).split(".")[0]
-        print("Input visual features: ", tuple(vis.shape))
+        say("Input visual features: ", tuple(vis.shape))
     if args.text_path is not None:
         text_strs, wbs = extract.load_text(args.text_path)
         if fname is None:
             fname = os.path.basename(args.text_path).split(".")[0]
     if args.audio_path is not None and "a" in mod:
-        print("Loading audio...")
+        say("Loading audio...")
         wav = torch.from_numpy(np.asarray(jaudio.load_wav(args.audio_path)).astype(np.float32))
         audio = jaudio.wav2filterbanks(wav[None].to(eng.device), engine=eng)[0]       # load_audio (:440-475)
-        print("Input audio mel: ", tuple(audio.shape))
+        say("Input audio mel: ", tuple(audio.shape))
         am = torch.ones((1, audio.shape[1] // 4), device=eng.device)
     if fname is None and args.audio_path is not None:
         fname = os.path.basename(args.audio_path).split(".")[0]
@@ -545,8 +597,8 @@ def cmd_inference_embs(argv):
         else:
             from .xlmr import roberta_embeddings
             text = roberta_embeddings(_load_xlmr(eng, args.xlmr_checkpoint), _load_tokenizer(args.tokenizer), text_strs)
-    print("Extracting JEGAL embeddings...")
-    print("------------------------------------------------")
+    say("Extracting JEGAL embeddings...")
+    say("------------------------------------------------")
     out = jg.forward_inference(visual_feats=vis, visual_mask=mask, text=text, audio=audio, audio_mask=am,
                                word_boundaries=wbs if mod != "v" else None)
     gesture = content = None
@@ -558,18 +610,11 @@ def cmd_inference_embs(argv):
         content = out
     if gesture is not None:
         gesture = eng.l2norm(gesture[0]).cpu().numpy()                       # F.normalize(p=2, dim=-1), [0], .cpu().numpy() (:629-637)
-        print("Extracted gesture embeddings: ", gesture.shape)
+        say("Extracted gesture embeddings: ", gesture.shape)
     if content is not None:
         content = eng.l2norm(content[0]).cpu().numpy()
-        print("Extracted content embeddings: ", content.shape)
-    print("------------------------------------------------")
-    feat = {"gesture_emb": gesture, "content_emb": content,
-            "info": {"fname": fname, "word_boundaries": None if wbs is None else wbs[0], "text": None if text_strs is None else text_strs[0]}}
-    output_fname = os.path.join(args.res_dir, fname + ".pkl")
-    with open(output_fname, "wb") as f:
-        pickle.dump(feat, f)
-    print("Saved the embeddings: ", output_fname)
-    return 0
+        say("Extracted content embeddings: ", content.shape)
+    return gesture, content, fname, wbs, text_strs
 
 
 def main(argv=None):

@@ -447,3 +447,60 @@ def test_inference_embs_command_config0_one_call(tmp_path, monkeypatch):
     with pytest.raises(ValueError):
         drivers.main(["inference_embs", "--modalities", "va", "--checkpoint_path_gestsync", "synthetic", "--checkpoint_path_jegal", "synthetic",
                       "--res_dir", res, "--audio_path", os.path.join(gold, "sample1.wav"), "--text_path", str(txt)])
+
+
+def test_inference_embs_audit_flag_reports_the_error_of_the_default_mode(tmp_path, monkeypatch, capsys):
+    """`inference_embs ... --audit`: the clip runs a second time on a JG_PREC_FP32 engine with the same checkpoints and the
+    driver prints rel-L2 / max-abs of the embeddings it saved against that run -- the 1e-3 contract checked on the caller's own clip
+    where no CPU reference is at hand.  Here the reference IS at hand (the oracle chain): the audit engine must agree with it to
+    2e-5, so the printed figures are the default mode's true error; and `--precision 6` writes the audit embeddings themselves."""
+    import json
+    from jegal_amd import audio
+    from test_gpu_xlmr import StubTokenizer
+    monkeypatch.setattr(drivers, "_load_tokenizer", lambda name: StubTokenizer())
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    txt = tmp_path / "sample1.txt"
+    txt.write_text(json.load(open(os.path.join(gold, "load_text.json")))["sample1"]["file"], encoding="utf-8")
+    rng = np.random.default_rng(4243)
+    T = 40
+    crops = rng.integers(0, 256, (T, 270, 480, 3), dtype=np.uint8)
+    crops[:, :110] = 0
+    np.save(tmp_path / "sample1.npy", crops)
+    res = str(tmp_path / "res")
+    common = ["--checkpoint_path_gestsync", "synthetic", "--checkpoint_path_jegal", "synthetic", "--video_path", str(tmp_path / "sample1.npy"),
+              "--audio_path", os.path.join(gold, "sample1.wav"), "--text_path", str(txt), "--xlmr_checkpoint", "synthetic", "--tokenizer", "stub"]
+    capsys.readouterr()
+    assert drivers.main(["inference_embs", "--modalities", "vta", "--audit", "--res_dir", res] + common) == 0
+    text = capsys.readouterr().out
+    line = [ln for ln in text.splitlines() if ln.startswith("Audit (fp32 engine")]
+    assert len(line) == 1 and "gesture rel-L2" in line[0] and "content rel-L2" in line[0] and "WARNING" not in text, text
+    got = pickle.load(open(os.path.join(res, "sample1.pkl"), "rb"))
+    res32 = str(tmp_path / "res32")
+    from jegal_amd._lib import Engine
+    Engine.get("cuda:0").close()                       # the process-wide driver engine is finalized in the default mode: a new one for mode 6
+    try:
+        assert drivers.main(["inference_embs", "--modalities", "vta", "--precision", "6", "--res_dir", res32] + common) == 0
+    finally:
+        Engine.get("cuda:0").close()                   # ... and the later tests get a default-mode engine again
+    got32 = pickle.load(open(os.path.join(res32, "sample1.pkl"), "rb"))
+    ref_text = json.load(open(os.path.join(gold, "load_text.json")))["sample1"]
+    gsd, jsd, xsd = O.tensors(synth.gestsync_state_dict(include_unused=False)), O.tensors(synth.jegal_state_dict()), synth.xlmr_state_dict()
+    wbs = ref_text["word_boundaries"]
+    with torch.no_grad():
+        feats = O.gestsync_clip_feats(gsd, torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)))
+        wav = audio.load_wav(os.path.join(gold, "sample1.wav")).astype("float32")
+        mel = O.wav2filterbanks(wav[None], torch.from_numpy(audio.mel_filterbank()))
+        enc = StubTokenizer()([ref_text["text"][0].split(" ")])
+        states = O.xlmr_forward(xsd, enc["input_ids"].numpy(), enc["attention_mask"].numpy())
+        pack = (states, enc["attention_mask"], [ref_text["text"][0].split(" ")], enc["input_ids"], enc["offset_mapping"])
+        g, c = O.jegal_forward_inference(jsd, visual_feats=feats[None], visual_mask=torch.ones(1, T), text=pack, audio=mel,
+                                         audio_mask=torch.ones(1, mel.shape[1] // 4), word_boundaries=wbs)
+        g, c = O.l2_normalize(g[0]).numpy(), O.l2_normalize(c[0]).numpy()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print(f"\n--precision 6 vs the oracle chain: gesture {rel(got32['gesture_emb'], g):.2e} content {rel(got32['content_emb'], c):.2e}; "
+          f"default vs oracle: gesture {rel(got['gesture_emb'], g):.2e} content {rel(got['content_emb'], c):.2e}\n{line[0]}")
+    assert rel(got32["gesture_emb"], g) < 2e-5 and rel(got32["content_emb"], c) < 2e-5
+    # the printed audit figures are the default mode's distance to the oracle, to the audit mode's own 2e-5
+    import re
+    nums = [float(x) for x in re.findall(r"rel-L2 ([0-9.e+-]+)", line[0])]
+    assert abs(nums[0] - rel(got["gesture_emb"], g)) < 5e-5 and abs(nums[1] - rel(got["content_emb"], c)) < 5e-5
