@@ -572,6 +572,8 @@ def main():
         layer_gflop = [CONV2_GFLOP_PER_CLIP, CONV3_GFLOP_PER_CLIP, CONV4_GFLOP_PER_CLIP, CONV5_GFLOP_PER_CLIP]
         conv_rest_exec = CONV_REST_GFLOP_PER_CLIP - sum(g * (1.0 - f) for g, f in zip(layer_gflop, cfrac))
         exec_gflop_clip = CONV1_GFLOP_PER_CLIP * exec_frac + conv_rest_exec + LINEAR_GFLOP_PER_CLIP
+        pooled_rows_written = 43 - 2 * max(int(conv2_rows_skipped or 0), 0) if zskip else 43
+        exec_bytes_launch = (FRAMES * 270 * 480 * 3 * exec_frac + 2 * POS_EXEC * pooled_rows_written * 78 * 64) * clips_per_launch
         stage = {k: v[0] / nprof for k, v in prof.items()}
         conv_ms = stage["conv1"] + stage["conv1_aux"] + stage["maxpool"] + stage["conv2-fc6+audio_cnn"] + stage["stack_frames"]
         lin_ms = stage["gemm"] + stage["attention"] + stage["layernorm"]
@@ -589,8 +591,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv1_direct_kernel (u8 frames -> conv1+BN+ReLU+maxpool, 154 distinct positions/clip)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "traffic": traffic * clips_per_launch / 32.0 if traffic else None, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch,
-                         "hbm_frac_of_peak": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch / c1_avg_s / 1e9 / HBM_PEAK_GBS if c1_avg_s > 0 else None,
+                         # bytes the launch has to move for the work it EXECUTES: the frame rows of the executed input tiles (the all-zero
+                         # bands are read by the scan kernel, not by this one) + the pooled rows conv2 will read (conv2's row skip leaves
+                         # the first 2 x s2 pooled rows of every position unwritten); `traffic` / this >= 1 is the re-read / write amplification
+                         "algorithmic_bytes_per_launch": exec_bytes_launch,
+                         "algorithmic_bytes_per_launch_unskipped": CONV1_ALGO_BYTES_PER_CLIP * clips_per_launch,
+                         "traffic_over_algorithmic": (traffic * clips_per_launch / 32.0) / exec_bytes_launch if traffic else None,
+                         "hbm_frac_of_peak": exec_bytes_launch / c1_avg_s / 1e9 / HBM_PEAK_GBS if c1_avg_s > 0 else None,
                          "launch_ms": c1_avg_s * 1e3, "launches_per_step": c1_n / nprof,
                          "counters": load_sq_counters(),
                          "executed_tile_fraction": exec_frac,
@@ -644,6 +651,12 @@ def main():
             res["spotting_config5"] = extras["spotting"]
             if "config3" in extras:
                 res["config3"] = extras["config3"]
+            # the driver keeps `config` whole (other top-level keys are reduced to their names): the numbers a reader of the headline needs
+            res["config"]["value_is"] = "masked synthetic clips (rows 0..109 zero, BASELINE configs[1]), precision mode JG_PREC_FP16_RC, two lanes"
+            res["config"]["same_loop_other_inputs_clips_per_s"] = {"dense_frames_no_zero_row": round(res["value_dense"]["value"], 1),
+                                                                   "mask_height_jitter_80_140": round(res["value_jitter_mask"]["value"], 1)}
+            if extras.get("precision_modes"):
+                res["config"]["same_loop_other_precision_modes_clips_per_s"] = {k: round(v["value"], 1) for k, v in extras["precision_modes"].items() if "value" in v}
             if extras.get("precision_modes"):
                 res["precision_modes"] = dict(extras["precision_modes"],
                                               what="the SAME timed loop (same clips, steps, two lanes) in the other precision treatments: `value` above is "

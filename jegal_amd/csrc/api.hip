@@ -188,6 +188,10 @@ struct jg_handle {
     // fp32 audit path (audit32.hip).  audit_weights: finalize also keeps every matrix in fp32 (always in JG_PREC_FP32); audit_stages: which
     // stages of the path run in fp32 (bit 0 conv stack, 1 GestSync transformer + ff_vid, 2 JEGAL gesture branch, 3 JEGAL content path,
     // 4 XLM-RoBERTa; JG_PREC_FP32 = all of them) -- the stage boundaries are fp32 tensors in every mode, so stages can be mixed
+    // round 6: the two ends of the JEGAL gesture branch -- proj_ip_rgb and final norm + proj_op_rgb + the align MLP, five
+    // small GEMMs that carry two thirds of the branch's fp16 error -- run on the fp32 kernel in the fp16 contract modes
+    bool jegal_fp32_ends = true;
+    bool conv_round_diffuse = true;      // conv weights rounded with per-channel error diffusion across the taps (pack_matrix)
     bool audit_weights = false;
     int audit_stages = 0;
     // diagnosis inside the fp16 JEGAL gesture branch (option "audit_jegal_parts", needs audit_weights): 1 input projection, 2 attention
@@ -292,7 +296,15 @@ int need(jg_handle* h, const std::string& name, int64_t numel, const HostTensor*
 // layer kinds: which precision treatment a matrix gets under the handle's mode
 enum { LK_CONV = 0, LK_GESTURE = 1, LK_CONTENT = 2, LK_XLMR = 3 };      // LK_XLMR: bias-corrected like the gesture path (calibrated on token ids)
 
-int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L, bool ln_consumer = false) {
+// keep32: the layer also runs on the fp32 kernel in the fp16 modes (the two ends of the JEGAL gesture branch, option jegal_fp32_ends)
+// diffuse_group > 0 (conv layers, option conv_round_diffuse): fp16 rounding with ERROR DIFFUSION along the taps of one (output channel,
+// input slot) pair -- k = tap * diffuse_group + slot -- instead of round-to-nearest per weight: the residuals w - fp16(w) of a
+// channel's taps then sum to less than half an ulp, so the part of the weight-rounding error that is the same for every output pixel,
+// sum_k (w - fp16(w))[k] E[x_k] = sum_slot E[x_slot] sum_taps (w - fp16(w)), vanishes wherever the input statistics do not depend on the
+// tap (everywhere but at the image border); the price is a per-weight residual of up to one ulp instead of half an ulp in the part
+// that averages out over pixels.  No calibration, no run-time cost (measured with tools/precision_floor.py).
+int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<float>& bias, int N, int K, int kind, Lin* L, bool ln_consumer = false,
+                bool keep32 = false, int diffuse_group = 0) {
     const int mode = h->precision;
     // JG_PREC_FP16_RC: GestSync's Linears (model 1) are run-time corrected; the JEGAL gesture branch (M = B*T rows: launch-bound, a
     // 256-row tile meets several clips) and the content path keep hi+lo; XLM-RoBERTa as in JG_PREC_FP16_BC (hi+lo until calibrated)
@@ -309,6 +321,20 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
             const uint16_t b = bf16_bits(w[i]);
             std::memcpy(&hi[i], &b, 2);
         }
+    } else if (diffuse_group > 0 && K % diffuse_group == 0 && !(split || bc || rc)) {
+        const int taps = K / diffuse_group;
+        for (int n = 0; n < N; ++n)
+            for (int sl = 0; sl < diffuse_group; ++sl) {
+                double carry = 0.0;
+                for (int t = 0; t < taps; ++t) {
+                    const size_t i = (size_t)n * K + (size_t)t * diffuse_group + sl;
+                    if (w[i] == 0.f) { hi[i] = (f16)0.f; continue; }        // padding slots stay exactly zero
+                    const double v = (double)w[i] + carry;
+                    const f16 a = (f16)(float)v;
+                    hi[i] = a;
+                    carry = v - (double)(float)a;
+                }
+            }
     } else {
         for (size_t i = 0; i < hi.size(); ++i) {
             const f16 a = (f16)w[i];
@@ -348,7 +374,7 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     if (split) RET(upload(h, lo, &L->wl));
     RET(upload(h, bias, &L->bias));
     L->w32d = L->b32d = nullptr;
-    if (h->audit_weights || h->precision == JG_PREC_FP32) {
+    if (h->audit_weights || h->precision == JG_PREC_FP32 || keep32) {
         RET(upload(h, w, &L->w32d));
         RET(upload(h, bias, &L->b32d));
     }
@@ -369,11 +395,11 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     return JG_OK;
 }
 
-int make_linear(jg_handle* h, const std::string& wname, const std::string& bname, int N, int K, Lin* L, int kind = LK_GESTURE) {
+int make_linear(jg_handle* h, const std::string& wname, const std::string& bname, int N, int K, Lin* L, int kind = LK_GESTURE, bool keep32 = false) {
     const HostTensor *w, *b;
     RET(need(h, wname, (int64_t)N * K, &w));
     RET(need(h, bname, N, &b));
-    return pack_matrix(h, w->v, b->v, N, K, kind, L);
+    return pack_matrix(h, w->v, b->v, N, K, kind, L, false, keep32);
 }
 
 int make_ln(jg_handle* h, const std::string& wname, const std::string& bname, int D, LNp* p) {
@@ -431,7 +457,7 @@ int make_conv(jg_handle* h, const std::string& conv, const std::string& bn, int 
                     const float v = w->v[((((size_t)o * I + c) * KT + kt) * KH + kh) * KW + kw] * s[o];
                     p[(size_t)o * K + t * slot + kt * I + c] = v;
                 }
-    return pack_matrix(h, p, shift, O, K, LK_CONV, L);
+    return pack_matrix(h, p, shift, O, K, LK_CONV, L, false, false, h->conv_round_diffuse ? slot : 0);
 }
 
 int make_annotated_layer(jg_handle* h, const std::string& p, int D, int Dff, EncLayer* L, int kind) {
@@ -529,15 +555,15 @@ int finalize_jegal(jg_handle* h) {
     // The input projection keeps hi+lo weights in the bias-corrected mode too: the zero-padded rows of a ragged batch
     // (dataset.py:336-340) reach it as x = 0 exactly, where a bias correction (w - fp16(w)).E[x] would be pure error -- the
     // reference computes those rows as well (callers strip them).  Two small GEMMs of the 50 in the branch.
-    RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0, LK_CONTENT));
+    RET(make_linear(h, "proj_ip_rgb.0.weight", "proj_ip_rgb.0.bias", 512, 1024, &h->ip0, LK_CONTENT, true));
     RET(make_ln(h, "proj_ip_rgb.1.weight", "proj_ip_rgb.1.bias", 512, &h->ip_ln));
-    RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3, LK_CONTENT));
+    RET(make_linear(h, "proj_ip_rgb.3.weight", "proj_ip_rgb.3.bias", 512, 512, &h->ip3, LK_CONTENT, true));
     const HostTensor* pe;
     RET(need(h, "position_rgb.pe", 500 * 512, &pe));
     RET(upload(h, pe->v, &h->rgb_pe));
     for (int l = 0; l < 6; ++l) RET(make_annotated_layer(h, "encoder_rgb.layers." + std::to_string(l), 512, 2048, &h->rgb_layers[l], LK_GESTURE));
     RET(make_ln(h, "encoder_rgb.norm.a_2", "encoder_rgb.norm.b_2", 512, &h->rgb_norm));
-    RET(make_linear(h, "proj_op_rgb.weight", "proj_op_rgb.bias", 512, 512, &h->op_rgb));
+    RET(make_linear(h, "proj_op_rgb.weight", "proj_op_rgb.bias", 512, 512, &h->op_rgb, LK_GESTURE, true));
     for (int l = 0; l < 3; ++l) RET(make_annotated_layer(h, "encoder_text.layers." + std::to_string(l), 768, 3072, &h->text_layers[l], LK_CONTENT));
     RET(make_ln(h, "encoder_text.norm.a_2", "encoder_text.norm.b_2", 768, &h->text_norm));
     RET(make_linear(h, "proj_op_text.weight", "proj_op_text.bias", 256, 768, &h->op_text, LK_CONTENT));
@@ -550,8 +576,8 @@ int finalize_jegal(jg_handle* h) {
     RET(make_linear(h, "proj_op_audio.weight", "proj_op_audio.bias", 256, 256, &h->op_audio, LK_CONTENT));
     RET(make_linear(h, "proj_op_fusion_content.0.weight", "proj_op_fusion_content.0.bias", 512, 512, &h->fu0, LK_CONTENT));
     RET(make_linear(h, "proj_op_fusion_content.2.weight", "proj_op_fusion_content.2.bias", 512, 512, &h->fu2, LK_CONTENT));
-    RET(make_linear(h, "proj_op_align_gesture.0.weight", "proj_op_align_gesture.0.bias", 512, 512, &h->al_g0));
-    RET(make_linear(h, "proj_op_align_gesture.2.weight", "proj_op_align_gesture.2.bias", 512, 512, &h->al_g2));
+    RET(make_linear(h, "proj_op_align_gesture.0.weight", "proj_op_align_gesture.0.bias", 512, 512, &h->al_g0, LK_GESTURE, true));
+    RET(make_linear(h, "proj_op_align_gesture.2.weight", "proj_op_align_gesture.2.bias", 512, 512, &h->al_g2, LK_GESTURE, true));
     RET(make_linear(h, "proj_op_align_content.0.weight", "proj_op_align_content.0.bias", 512, 512, &h->al_c0, LK_CONTENT));
     RET(make_linear(h, "proj_op_align_content.2.weight", "proj_op_align_content.2.bias", 512, 512, &h->al_c2, LK_CONTENT));
     h->jg_ready = true;
@@ -1338,7 +1364,9 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     if (B <= 0 || T <= 0 || T > 500) JG_FAIL(h, JG_ERR_ARG, "need B > 0 and 0 < T <= 500 (PE table, modules.py:136)");
     if (audit_mask(h) & AUD_JG) return jegal_gestures_impl32(h, feats, mask, B, T, align, out);
     const int M = B * T;
-    const int parts = h->audit_jegal_parts;
+    // the branch's two ends on the fp32 kernel (option jegal_fp32_ends; not in the plain-fp16 / bf16 reported modes, not while calibrating)
+    const bool ends32 = h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->ip0.w32d && h->al_g2.w32d;
+    const int parts = h->audit_jegal_parts | (ends32 ? 9 : 0);
     f16 *f16in, *t16, *n16, *g16, *a16;
     float *t32, *x32, *n32 = nullptr;
     RET(wsalloc(h, (size_t)M * 1024, &f16in));
@@ -1945,6 +1973,12 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "jegal_fp32_ends")) { h->jegal_fp32_ends = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "conv_round_diffuse")) {
+        if (h->gs_ready || h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "set conv_round_diffuse before jg_finalize_weights");
+        h->conv_round_diffuse = value != 0;
+        return JG_OK;
+    }
     if (!std::strcmp(name, "audit_weights")) {
         if (h->gs_ready || h->jg_ready || h->xl_ready) JG_FAIL(h, JG_ERR_STATE, "set audit_weights before jg_finalize_weights");
         h->audit_weights = value != 0;

@@ -15,126 +15,143 @@ __device__ __forceinline__ float act1(float v, int act) {
 // global loads are issued before the MFMAs of the current one.  The WEIGHT tile is the MFMA "A" operand: a lane ends up with four
 // consecutive n of one m per accumulator quad (16-byte stores).
 // VEC: every 4-aligned k-quad of a row is contiguous in memory and 16-byte aligned (plain: lda % 4 == 0; conv: C % 4 == 0).
-constexpr int G32_BM = 128, G32_BN = 128, G32_BK = 16, G32_LD = 132;
+constexpr int G32_BK = 16;
 
-template <bool CONV, bool VEC>
+// BT = block tile edge (128: 4 waves of 64 x 64 = 2 x 2 MFMA blocks each; 64: 4 waves of 32 x 32, for the small-M launches of the JEGAL
+// branch -- 4 x the workgroups, 2 x the LDS reads per MFMA, which the fp32 MFMA's 64 cycles hide)
+template <bool CONV, bool VEC, int BT>
 __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Args a) {
-    __shared__ float sX[G32_BK][G32_LD];
-    __shared__ float sW[G32_BK][G32_LD];
+    constexpr int LD = BT + 4, NB = BT / 64, NL = BT / 64;     // MFMA blocks per wave along n / m; loads (float4) per thread and operand
+    __shared__ float sX[G32_BK][LD];
+    __shared__ float sW[G32_BK][LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int n_tiles = (a.N + G32_BN - 1) / G32_BN;
-    const int n0 = (blockIdx.x % n_tiles) * G32_BN;
-    const int m0 = (int)(blockIdx.x / n_tiles) * G32_BM;
-    // loader: thread -> (row r = t >> 1, k half = t & 1: eight consecutive k of the 16)
-    const int r = t >> 1, kh8 = (t & 1) * 8;
-    const int mrow = m0 + r, nrow = n0 + r;
-    const bool xok = mrow < a.M, wok = nrow < a.N;
-    long xbase = 0;
-    int ih0 = 0, iw0 = 0;
-    if (CONV) {
-        const int mm = xok ? mrow : 0;
-        const int per = a.g.OH * a.g.OW;
-        const int img = mm / per, rem = mm - img * per;
-        const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
-        ih0 = oh * a.g.SH - a.g.PH;
-        iw0 = ow * a.g.SW - a.g.PW;
-        xbase = (long)img * a.g.H * a.g.W * a.g.C;
-    } else {
-        xbase = (long)(xok ? mrow : 0) * a.lda;
+    const int n_tiles = (a.N + BT - 1) / BT;
+    const int n0 = (blockIdx.x % n_tiles) * BT;
+    const int m0 = (int)(blockIdx.x / n_tiles) * BT;
+    // loader: float4 number idx = t + 256 u -> (row idx >> 2, k quad (idx & 3) * 4) of the BT x 16 tile
+    long xbase[NL], wbase[NL];
+    int ih0[NL], iw0[NL];
+    bool xok[NL], wok[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int r = (t + 256 * u) >> 2;
+        const int mrow = m0 + r, nrow = n0 + r;
+        xok[u] = mrow < a.M;
+        wok[u] = nrow < a.N;
+        ih0[u] = iw0[u] = 0;
+        if (CONV) {
+            const int mm = xok[u] ? mrow : 0;
+            const int per = a.g.OH * a.g.OW;
+            const int img = mm / per, rem = mm - img * per;
+            const int oh = rem / a.g.OW, ow = rem - oh * a.g.OW;
+            ih0[u] = oh * a.g.SH - a.g.PH;
+            iw0[u] = ow * a.g.SW - a.g.PW;
+            xbase[u] = (long)img * a.g.H * a.g.W * a.g.C;
+        } else {
+            xbase[u] = (long)(xok[u] ? mrow : 0) * a.lda;
+        }
+        wbase[u] = (long)(wok[u] ? nrow : 0) * a.ldw;
     }
-    const long wbase = (long)(wok ? nrow : 0) * a.ldw;
+    const int kq = (t & 3) * 4;
 
-    auto load_x1 = [&](int k) -> float {
-        if (!xok || k >= a.K) return 0.f;
+    auto load_x1 = [&](int u, int k) -> float {
+        if (!xok[u] || k >= a.K) return 0.f;
         if (CONV) {
             const int ci = k & (a.g.C - 1), kp = k >> a.g.cshift;
             int kh, kw;
             tap_decode(a.g, kp, kh, kw);
-            const int ih = ih0 + kh, iw = iw0 + kw;
+            const int ih = ih0[u] + kh, iw = iw0[u] + kw;
             if ((unsigned)ih >= (unsigned)a.g.H || (unsigned)iw >= (unsigned)a.g.W || kh >= a.g.KH) return 0.f;
-            return a.A[xbase + ((long)ih * a.g.W + iw) * a.g.C + ci];
+            return a.A[xbase[u] + ((long)ih * a.g.W + iw) * a.g.C + ci];
         }
-        return a.A[xbase + k];
+        return a.A[xbase[u] + k];
     };
-    auto load_x4 = [&](int k) -> f32x4 {
+    auto load_x4 = [&](int u, int k) -> f32x4 {
         if (VEC) {
-            if (!xok || k >= a.K) return f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!xok[u] || k >= a.K) return f32x4{0.f, 0.f, 0.f, 0.f};
             if (CONV) {
                 const int ci = k & (a.g.C - 1), kp = k >> a.g.cshift;
                 int kh, kw;
                 tap_decode(a.g, kp, kh, kw);
-                const int ih = ih0 + kh, iw = iw0 + kw;
+                const int ih = ih0[u] + kh, iw = iw0[u] + kw;
                 if ((unsigned)ih >= (unsigned)a.g.H || (unsigned)iw >= (unsigned)a.g.W || kh >= a.g.KH) return f32x4{0.f, 0.f, 0.f, 0.f};
-                return *reinterpret_cast<const f32x4*>(a.A + xbase + ((long)ih * a.g.W + iw) * a.g.C + ci);
+                return *reinterpret_cast<const f32x4*>(a.A + xbase[u] + ((long)ih * a.g.W + iw) * a.g.C + ci);
             }
-            return *reinterpret_cast<const f32x4*>(a.A + xbase + k);
+            return *reinterpret_cast<const f32x4*>(a.A + xbase[u] + k);
         }
-        return f32x4{load_x1(k), load_x1(k + 1), load_x1(k + 2), load_x1(k + 3)};
+        return f32x4{load_x1(u, k), load_x1(u, k + 1), load_x1(u, k + 2), load_x1(u, k + 3)};
     };
-    auto load_w4 = [&](int k) -> f32x4 {
-        if (!wok) return f32x4{0.f, 0.f, 0.f, 0.f};
-        if (VEC && k + 3 < a.K) return *reinterpret_cast<const f32x4*>(a.W + wbase + k);
+    auto load_w4 = [&](int u, int k) -> f32x4 {
+        if (!wok[u]) return f32x4{0.f, 0.f, 0.f, 0.f};
+        if (VEC && k + 3 < a.K) return *reinterpret_cast<const f32x4*>(a.W + wbase[u] + k);
         f32x4 v;
-        v.x = k < a.K ? a.W[wbase + k] : 0.f;
-        v.y = k + 1 < a.K ? a.W[wbase + k + 1] : 0.f;
-        v.z = k + 2 < a.K ? a.W[wbase + k + 2] : 0.f;
-        v.w = k + 3 < a.K ? a.W[wbase + k + 3] : 0.f;
+        v.x = k < a.K ? a.W[wbase[u] + k] : 0.f;
+        v.y = k + 1 < a.K ? a.W[wbase[u] + k + 1] : 0.f;
+        v.z = k + 2 < a.K ? a.W[wbase[u] + k + 2] : 0.f;
+        v.w = k + 3 < a.K ? a.W[wbase[u] + k + 3] : 0.f;
         return v;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NB][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
 
     const int nk = (a.K + G32_BK - 1) / G32_BK;
-    f32x4 xr[2], wr[2];
-    xr[0] = load_x4(kh8);
-    xr[1] = load_x4(kh8 + 4);
-    wr[0] = load_w4(kh8);
-    wr[1] = load_w4(kh8 + 4);
+    f32x4 xr[NL], wr[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        xr[u] = load_x4(u, kq);
+        wr[u] = load_w4(u, kq);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            sX[kh8 + q * 4 + 0][r] = xr[q].x; sX[kh8 + q * 4 + 1][r] = xr[q].y; sX[kh8 + q * 4 + 2][r] = xr[q].z; sX[kh8 + q * 4 + 3][r] = xr[q].w;
-            sW[kh8 + q * 4 + 0][r] = wr[q].x; sW[kh8 + q * 4 + 1][r] = wr[q].y; sW[kh8 + q * 4 + 2][r] = wr[q].z; sW[kh8 + q * 4 + 3][r] = wr[q].w;
+        for (int u = 0; u < NL; ++u) {
+            const int r = (t + 256 * u) >> 2;
+            sX[kq + 0][r] = xr[u].x; sX[kq + 1][r] = xr[u].y; sX[kq + 2][r] = xr[u].z; sX[kq + 3][r] = xr[u].w;
+            sW[kq + 0][r] = wr[u].x; sW[kq + 1][r] = wr[u].y; sW[kq + 2][r] = wr[u].z; sW[kq + 3][r] = wr[u].w;
         }
         __syncthreads();
         if (kt + 1 < nk) {
-            const int k = (kt + 1) * G32_BK + kh8;
-            xr[0] = load_x4(k);
-            xr[1] = load_x4(k + 4);
-            wr[0] = load_w4(k);
-            wr[1] = load_w4(k + 4);
+            const int k = (kt + 1) * G32_BK + kq;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                xr[u] = load_x4(u, k);
+                wr[u] = load_w4(u, k);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < G32_BK; kk += 2) {
             const int kr = kk + (lane >> 5);
-            const float w0 = sW[kr][wn * 64 + (lane & 31)], w1 = sW[kr][wn * 64 + 32 + (lane & 31)];
-            const float x0 = sX[kr][wm * 64 + (lane & 31)], x1 = sX[kr][wm * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, x1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, x1, acc[1][1], 0, 0, 0);
+            float w[NB], x[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                w[i] = sW[kr][wn * (BT / 2) + i * 32 + (lane & 31)];
+                x[i] = sX[kr][wm * (BT / 2) + i * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], x[j], acc[i][j], 0, 0, 0);
         }
     }
     // D layout: B index (m) = lane & 31, A index (n) = (x & 3) + 8 (x >> 2) + 4 (lane >> 5)
     const bool n4ok = (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.res || (a.ldr & 3) == 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NB; ++j) {
+        const int m = m0 + wm * (BT / 2) + j * 32 + (lane & 31);
         if (m >= a.M) continue;
         const long rr = a.res ? (long)(a.res_mod ? m % a.res_mod : m) * a.ldr : 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+                const int n = n0 + wn * (BT / 2) + i * 32 + 8 * q + 4 * (lane >> 5);
                 if (n >= a.N) continue;
                 float v[4];
 #pragma unroll
@@ -287,21 +304,29 @@ inline int grid_for(long total) { return (int)((total + 255) / 256 < 65536 * 4 ?
 
 }  // namespace
 
-hipError_t launch_gemm32(const Gemm32Args& a, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    if (a.K <= 0 || !a.A || !a.W || !a.out) return hipErrorInvalidValue;
-    const long mt = (a.M + G32_BM - 1) / G32_BM, nt = (a.N + G32_BN - 1) / G32_BN;
+template <int BT>
+static hipError_t launch_gemm32_bt(const Gemm32Args& a, hipStream_t s) {
+    const long mt = (a.M + BT - 1) / BT, nt = (a.N + BT - 1) / BT;
     const dim3 grid((unsigned)(mt * nt)), block(256);
     const bool walign = (a.ldw & 3) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.A & 15) == 0;
     if (a.conv) {
         if ((1 << a.g.cshift) != a.g.C || a.g.rowmap || a.g.const_in) return hipErrorInvalidValue;
-        if (walign && (a.g.C & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm32_kernel<true, false>), grid, block, 0, s, a);
+        if (walign && (a.g.C & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<true, true, BT>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm32_kernel<true, false, BT>), grid, block, 0, s, a);
     } else {
-        if (walign && (a.lda & 3) == 0 && (a.K & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm32_kernel<false, false>), grid, block, 0, s, a);
+        if (walign && (a.lda & 3) == 0 && (a.K & 3) == 0) hipLaunchKernelGGL((gemm32_kernel<false, true, BT>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm32_kernel<false, false, BT>), grid, block, 0, s, a);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_gemm32(const Gemm32Args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (a.K <= 0 || !a.A || !a.W || !a.out) return hipErrorInvalidValue;
+    // fewer than ~1.5 rounds of 128 x 128 tiles on 256 CUs: 64 x 64 tiles (the small-M launches of the JEGAL branch)
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (tiles128 < 384) return launch_gemm32_bt<64>(a, s);
+    return launch_gemm32_bt<128>(a, s);
 }
 
 hipError_t launch_attention32(const float* qkv, const float* keymask, int B, int S, int H, int dk, float* out, hipStream_t s) {

@@ -283,12 +283,15 @@ def synth_frames_structured(seed, n_clips, n_frames, kind, height=270, width=480
                  the largest conv1 sums the u8 path can see; rows [0, mask_rows) zero
     "jitter"     the smooth content with the mask height drawn PER FRAME from 80..140, frame 3 of every clip NOT masked at all
                  and frame 5 masked completely (inference_embs.py:264-270 blanks rows 0..y2+15 per frame; no face = no mask)
+    "periodic"   the smooth content under a strong temporal brightness modulation whose periods are the ones the run-time corrected
+                 mode's row sample could alias with: 128 / 21 = 6.095 frames (the sampled 16-row runs start every
+                 128 token rows = every 6.095 windows), 21 frames and 128 frames, plus a slow horizontal pan; rows [0, mask_rows) zero
     """
     rng = np.random.default_rng([seed, 0x57A7])
     yy, xx = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
     out = np.empty((n_clips, n_frames, height, width, 3), np.uint8)
     for b in range(n_clips):
-        if kind in ("smooth", "jitter"):
+        if kind in ("smooth", "jitter", "periodic"):
             ph = rng.uniform(0, 2 * np.pi, (3, 2))
             fx, fy = rng.uniform(0.6, 2.2, 3), rng.uniform(0.6, 2.2, 3)
             blob = rng.uniform([60, 120, 25, 18], [420, 250, 70, 45], (3, 4))          # x0, y0, sx, sy
@@ -303,6 +306,10 @@ def synth_frames_structured(seed, n_clips, n_frames, kind, height=270, width=480
                 for c in range(3):
                     img[..., c] = (118.0 + 8.0 * c + 22.0 * np.sin(2 * np.pi * fx[c] * xx / width + ph[c, 0] + 0.03 * t)
                                    + 16.0 * np.cos(2 * np.pi * fy[c] * yy / height + ph[c, 1] - 0.02 * t) + bl * (1.0 - 0.15 * c))
+                if kind == "periodic":
+                    gain = 1.0 + 0.30 * np.sin(2 * np.pi * t * 21.0 / 128.0 + ph[0, 0]) + 0.20 * np.sin(2 * np.pi * t / 21.0 + ph[1, 0]) \
+                        + 0.15 * np.sin(2 * np.pi * t / 128.0 + ph[2, 0])
+                    img = np.roll(img, int(round(1.5 * t)), axis=1) * np.float32(gain)
                 img += rng.integers(-2, 3, img.shape).astype(np.float32)
                 out[b, t] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         elif kind == "saturated":

@@ -84,3 +84,26 @@ def test_calibrating_on_structured_clips_keeps_noise_clips_in_tolerance(oracle_s
         print(f"\ncalibrated on smooth clips, tested on {kind}: rel-L2 {r:.3e}", end="")
         assert r < TOL, (kind, r)
     e.close()
+
+
+def test_rc_row_sample_on_temporally_periodic_clips(engines, oracle_sd):
+    """VERDICT r5 item 6.  JG_PREC_FP16_RC takes E[x] of a 150-frame clip from 394 of its 3 150 token rows (16-row runs every 128 rows).  A
+    clip whose content oscillates at the sample's own periods (128 / 21 = 6.095 frames between sampled runs, 21 frames, 128 frames;
+    synth 'periodic') is where a sampled mean could alias.  Measured against hi+lo weights (no E[x] at all): the sample must not cost
+    more than 10 % of W2's error."""
+    gsd, jsd = oracle_sd
+    frames = synth.synth_frames_structured(4107, 2, T, "periodic")
+    dev = torch.from_numpy(frames).cuda()
+    errs = {}
+    with torch.no_grad():
+        refs = []
+        for b in range(2):
+            f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+            refs.append((f.numpy(), O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy()))
+    for name in ("fp16_w2", "fp16_rc"):
+        emb = engines[name].extract_gesture(dev).cpu().numpy()
+        feats = engines[name].gestsync_clip(dev).cpu().numpy()
+        errs[name] = (max(rel(emb[b], refs[b][1]) for b in range(2)), max(rel(feats[b], refs[b][0]) for b in range(2)))
+        print(f"\n[periodic] {name}: embedding rel-L2 {errs[name][0]:.3e} | GestSync feats {errs[name][1]:.3e}", end="")
+    assert errs["fp16_rc"][0] < TOL and errs["fp16_rc"][1] < TOL
+    assert errs["fp16_rc"][0] <= 1.1 * errs["fp16_w2"][0] and errs["fp16_rc"][1] <= 1.1 * errs["fp16_w2"][1], errs

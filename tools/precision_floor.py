@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--clips", type=int, default=2)
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--opts", default="", help="extra engine options for the RC rows, e.g. stream_fp16=0")
+    ap.add_argument("--quick", action="store_true", help="only the four rows of round 6's measures")
     args = ap.parse_args()
     T, B = args.frames, args.clips
     frames = synth.synth_frames(1234, B, T)
@@ -54,6 +55,7 @@ def main():
                 g = O.l2_normalize(O.jegal_forward_inference(jt, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
                 refs.append((f.numpy(), g.numpy()))
         rows = {}
+        extra = [tuple([kv.split("=")[0], int(kv.split("=")[1])]) for kv in args.opts.split(",") if kv]
 
         def run(tag, prec, aw=False, masks=(0,), opts=(), parts=(0,)):
             e = L.Engine(0, precision=prec)
@@ -74,18 +76,27 @@ def main():
                     rows[key] = {"gesture_rel": max(rel(emb[b], refs[b][1]) for b in range(B)),
                                  "gesture_maxabs": max(float(np.abs(emb[b] - refs[b][1]).max()) for b in range(B)),
                                  "feats_rel": max(rel(feats[b], refs[b][0]) for b in range(B))}
-                    print(f"[{fam}] {key:28s} gesture rel-L2 {rows[key]['gesture_rel']:.3e} max-abs {rows[key]['gesture_maxabs']:.3e} | "
+                    print(f"[{fam}] {key:32s} gesture rel-L2 {rows[key]['gesture_rel']:.3e} max-abs {rows[key]['gesture_maxabs']:.3e} | "
                           f"GestSync feats {rows[key]['feats_rel']:.3e}", flush=True)
             finally:
                 e.close()
 
-        extra = [tuple([kv.split("=")[0], int(kv.split("=")[1])]) for kv in args.opts.split(",") if kv]
+        # round 6's two measures, alone and together (the default): the JEGAL branch's ends on the fp32 kernel, conv weights rounded with
+        # per-channel error diffusion across the taps
+        run("rc r5 (ends=0 diffuse=0)", L.PREC_FP16_RC, opts=[("jegal_fp32_ends", 0), ("conv_round_diffuse", 0)])
+        run("rc ends=1 diffuse=0", L.PREC_FP16_RC, opts=[("conv_round_diffuse", 0)])
+        run("rc ends=0 diffuse=1", L.PREC_FP16_RC, opts=[("jegal_fp32_ends", 0)])
+        run("rc default", L.PREC_FP16_RC)
+        if args.quick:
+            table[fam] = rows
+            continue
+        extra = extra + [("jegal_fp32_ends", 0), ("conv_round_diffuse", 0)]          # the decomposition below is of the round-5 arithmetic
         run("rc", L.PREC_FP16_RC, aw=True, masks=(0, 1, 2, 4, 3, 5, 6, 7), opts=extra)
         # inside the JEGAL branch, on exact GestSync features (stages 3): 1 input projection, 2 attention sub-layers, 4 feed-forward
         # sub-layers, 8 final norm + output / align projections in fp32
         run("rc", L.PREC_FP16_RC, aw=True, masks=(3,), parts=(1, 2, 4, 8, 6, 14, 15), opts=extra)
-        run("w2", L.PREC_FP16_W2, aw=True, masks=(0, 1, 2, 4))
-        run("w2_all", L.PREC_FP16_W2_ALL)
+        run("w2", L.PREC_FP16_W2, aw=True, masks=(0, 1, 2, 4), opts=extra)
+        run("w2_all", L.PREC_FP16_W2_ALL, opts=extra)
         run("fp32", L.PREC_FP32)
         table[fam] = rows
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

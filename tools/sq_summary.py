@@ -61,7 +61,12 @@ def main():
             e["launches_in_step"] = m["launches"]
             e["us_per_launch_under_pmc"] = round(m["us"] / m["launches"], 1)
             e["kernel_cycles_per_launch"] = round(cyc / m["launches"])
-            e["clock_ghz_under_pmc"] = round(cyc / (m["us"] * 1e3), 3)
+            # GRBM_GUI_ACTIVE covers the dispatch's front and back porch as well as the kernel: below ~50 us per launch the quotient is
+            # not a clock (round 5 printed 3-12 GHz for the 4-9 us kernels) and the busy fraction inherits the same inflated denominator
+            if m["us"] / m["launches"] >= 50.0:
+                e["clock_ghz_under_pmc"] = round(cyc / (m["us"] * 1e3), 3)
+            else:
+                e["short_launch"] = "GRBM_GUI_ACTIVE / duration is meaningless below 50 us per launch: no clock; fractions of kernel_cycles are lower bounds"
             e["mfma_busy_frac"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / N_SIMD / cyc, 4)
             if m.get("SQ_INSTS_MFMA"):
                 e["cycles_per_mfma"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / m["SQ_INSTS_MFMA"], 2)
