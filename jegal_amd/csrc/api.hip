@@ -57,6 +57,7 @@ struct Lin {            // packed Linear / folded conv:  [N][K] fp16 hi (+lo), f
     // run-time corrected mode (JG_PREC_FP16_RC; GestSync transformer Linears): single fp16 `wh` + a per-clip bias built from the clip's own
     // rows and the lo part (`wl_calib`), see gemm(); wherever that epilogue is not available the GEMM runs hi+lo instead
     bool rc = false;
+    int rc_type = 0;            // which GestSync Linear this is for option rc_layers: 1 qkv, 2 out_proj, 4 linear1 / ff_vid.0, 8 linear2
     bool bc_pending = false;    // LK_XLMR: no calibration yet -- the run-time GEMM keeps using hi+lo (wl == wl_calib); jg_calibrate_xlmr clears it
     f16* wl_calib = nullptr;
     float* mu = nullptr;        // device [K]: column sums of the A operand seen during calibration
@@ -190,6 +191,8 @@ struct jg_handle {
     // 4 XLM-RoBERTa; JG_PREC_FP32 = all of them) -- the stage boundaries are fp32 tensors in every mode, so stages can be mixed
     // round 6: the two ends of the JEGAL gesture branch -- proj_ip_rgb and final norm + proj_op_rgb + the align MLP, five
     // small GEMMs that carry two thirds of the branch's fp16 error -- run on the fp32 kernel in the fp16 contract modes
+    int rc_layers = 15;            // experiment (option "rc_layers"): which Linear types of the GestSync transformer get the run-time correction
+                                   // (mask of Lin::rc_type); the others run single fp16 WITHOUT a correction -- measurement only
     bool jegal_fp32_ends = true;
     bool conv_round_diffuse = true;      // conv weights rounded with per-channel error diffusion across the taps (pack_matrix)
     bool audit_weights = false;
@@ -315,7 +318,8 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
                                        : (mode == JG_PREC_FP16_W2 || mode == JG_PREC_FP16_W2_ALL || (mode == JG_PREC_FP16_BC && kind == LK_CONTENT) ||
                                           (rcm && !rc && kind != LK_XLMR));
     std::vector<f16> hi((size_t)N * K), lo;
-    if (split || bc || rc) lo.resize((size_t)N * K);
+    const bool want_lo = split || bc || rc || keep32;
+    if (want_lo) lo.resize((size_t)N * K);
     if (h->bf16) {                       // JG_PREC_BF16: single bf16 weights (the 16-bit container is re-typed by the bf16 build)
         for (size_t i = 0; i < hi.size(); ++i) {
             const uint16_t b = bf16_bits(w[i]);
@@ -339,7 +343,7 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
         for (size_t i = 0; i < hi.size(); ++i) {
             const f16 a = (f16)w[i];
             hi[i] = a;
-            if (split || bc || rc) lo[i] = (f16)(w[i] - (float)a);
+            if (want_lo) lo[i] = (f16)(w[i] - (float)a);
         }
     }
     L->N = N; L->K = K;
@@ -382,6 +386,7 @@ int pack_matrix(jg_handle* h, const std::vector<float>& w, const std::vector<flo
     L->rc = rc;
     L->bc_pending = false;
     if (rc) RET(upload(h, lo, &L->wl_calib));
+    if (keep32 && !split && !bc && !rc) RET(upload(h, lo, &L->wl_calib));      // the lo half for the split-operand kernel (gemm_x3)
     if (bc) {
         RET(upload(h, lo, &L->wl_calib));
         RET(walloc<float>(h, (size_t)K, &L->mu));
@@ -538,7 +543,9 @@ int finalize_gestsync(jg_handle* h) {
         RET(make_linear(h, p + ".linear2.weight", p + ".linear2.bias", 512, 2048, &L->ff2));
         RET(make_ln(h, p + ".norm1.weight", p + ".norm1.bias", 512, &L->n1));
         RET(make_ln(h, p + ".norm2.weight", p + ".norm2.bias", 512, &L->n2));
+        L->qkv.rc_type = 1; L->out.rc_type = 2; L->ff1.rc_type = 4; L->ff2.rc_type = 8;
     }
+    h->ff0.rc_type = 4;
     h->gs_ready = true;
     return JG_OK;
 }
@@ -624,7 +631,9 @@ int gemm(jg_handle* h, int stage, const f16* A, long lda, int M, const Lin& L, c
     if (g) a.g = *g;
     a.Wh = L.wh; a.Wl = (h->calib && L.bc) ? L.wl_calib : L.wl; a.ldw = L.K;
     const bool conv = g != nullptr;
-    if (L.rc) {
+    if (L.rc && L.rc_type && !(h->rc_layers & L.rc_type)) {
+        // experiment (option rc_layers): this Linear type runs single fp16 without its correction
+    } else if (L.rc) {
         // run-time correction: bias_clip = bias + lo . (mean of a sample of the clip's own rows), two small launches in front of the GEMM;
         // only the LDS-DMA kernel's fp16-row and LayerNorm-fused epilogues take it (launch_gemm), everything else runs hi+lo
         const bool ln_fused = e.ln && e.res16;
@@ -940,6 +949,22 @@ int gemm32(jg_handle* h, int stage, const float* A, long lda, int M, const Lin& 
     return timed(h, stage, [&] { return launch_gemm32(a, h->stream); });
 }
 
+// The same product on the fp16 matrix cores with split operands (audit32.h, GemmX3Args): A fp32, W = hi + lo, three MFMAs per fragment pair
+int gemm_x3(jg_handle* h, int stage, const float* A, long lda, int M, const Lin& L, float* out, const Epi32& e = Epi32()) {
+    const f16* lo = L.wl ? L.wl : L.wl_calib;
+    if (!L.wh || !lo) JG_FAIL(h, JG_ERR_STATE, "split-operand GEMM on a layer that was packed without its lo half");
+    GemmX3Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.Wh = L.wh; a.Wl = lo; a.ldw = L.K;
+    a.M = M; a.N = L.N; a.K = L.K;
+    a.bias = L.b32d ? L.b32d : L.bias;
+    a.res = e.res; a.ldr = e.ldr; a.res_mod = e.res_mod;
+    a.out = out; a.ldc = L.N;
+    a.relu = e.act == 1;
+    if (e.act > 1) JG_FAIL(h, JG_ERR_ARG, "gemm_x3: ReLU only");
+    return timed(h, stage, [&] { return launch_gemm_x3(a, h->stream); });
+}
+
 // conv stack over `nclip` temporal volumes -> conv_out (nclip*P, 512) fp32 (gestsync.py:34-87,308-325: conv + BatchNorm(eval, folded) + ReLU, two max-pools)
 int gs_conv_stack32(jg_handle* h, const void* src, int src_u8, long sb, long st, long sh, long sw, long sc, int nclip, int T, int pad, float* conv_out) {
     const int P = T + 2 * pad - 4;
@@ -1054,25 +1079,32 @@ int encoder_sublayers32(jg_handle* h, const EncLayer& L, int which, float* x32, 
 }
 
 // proj_ip_rgb + positional rows (jegal.py:25-28,84-85) on the fp32 kernels: feats (M,1024) -> x32 (M,512); t32: (M,512) scratch
-int jegal_input32(jg_handle* h, const float* feats, int M, int T, float* t32, float* x32) {
+// x3: on the fp16 matrix cores with split operands (gemm_x3: the fp16 modes' production path) instead of the fp32 MFMA (audit)
+int jegal_input32(jg_handle* h, const float* feats, int M, int T, float* t32, float* x32, bool x3 = false) {
+    auto G = [&](const float* A, long lda, const Lin& L, float* out, const Epi32& e) {
+        return x3 ? gemm_x3(h, JG_ST_GEMM, A, lda, M, L, out, e) : gemm32(h, JG_ST_GEMM, A, lda, M, L, out, e);
+    };
     float* t2;
     RET(wsalloc(h, (size_t)M * 512, &t2));
-    RET(gemm32(h, JG_ST_GEMM, feats, 1024, M, h->ip0, t32));
+    RET(G(feats, 1024, h->ip0, t32, Epi32()));
     RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(t32, h->ip_ln.w, h->ip_ln.b, M, 512, LN_STD, 1, t2, nullptr, h->stream); }));
     Epi32 p; p.res = h->rgb_pe; p.ldr = 512; p.res_mod = T;
-    return gemm32(h, JG_ST_GEMM, t2, 512, M, h->ip3, x32, p);
+    return G(t2, 512, h->ip3, x32, p);
 }
 
 // proj_op_rgb (+ proj_op_align_gesture) on the fp32 kernels from the final norm's fp32 output
-int jegal_tail32(jg_handle* h, const float* n32, int M, int align, float* out) {
-    if (!align) return gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, out);
+int jegal_tail32(jg_handle* h, const float* n32, int M, int align, float* out, bool x3 = false) {
+    auto G = [&](const float* A, const Lin& L, float* o, const Epi32& e) {
+        return x3 ? gemm_x3(h, JG_ST_GEMM, A, 512, M, L, o, e) : gemm32(h, JG_ST_GEMM, A, 512, M, L, o, e);
+    };
+    if (!align) return G(n32, h->op_rgb, out, Epi32());
     float *g32, *a32;
     RET(wsalloc(h, (size_t)M * 512, &g32));
     RET(wsalloc(h, (size_t)M * 512, &a32));
-    RET(gemm32(h, JG_ST_GEMM, n32, 512, M, h->op_rgb, g32));
+    RET(G(n32, h->op_rgb, g32, Epi32()));
     Epi32 f; f.act = 1;
-    RET(gemm32(h, JG_ST_GEMM, g32, 512, M, h->al_g0, a32, f));
-    return gemm32(h, JG_ST_GEMM, a32, 512, M, h->al_g2, out);
+    RET(G(g32, h->al_g0, a32, f));
+    return G(a32, h->al_g2, out, Epi32());
 }
 
 int jegal_gestures_impl32(jg_handle* h, const float* feats, const float* mask, int B, int T, int align, float* out) {
@@ -1365,8 +1397,9 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     if (audit_mask(h) & AUD_JG) return jegal_gestures_impl32(h, feats, mask, B, T, align, out);
     const int M = B * T;
     // the branch's two ends on the fp32 kernel (option jegal_fp32_ends; not in the plain-fp16 / bf16 reported modes, not while calibrating)
-    const bool ends32 = h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->ip0.w32d && h->al_g2.w32d;
+    const bool ends32 = h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->ip0.b32d && h->al_g2.b32d;
     const int parts = h->audit_jegal_parts | (ends32 ? 9 : 0);
+    const bool ends_x3 = ends32 && !(h->audit_jegal_parts & 9);          // production: split operands on the fp16 matrix cores; diagnosis: fp32 MFMA
     f16 *f16in, *t16, *n16, *g16, *a16;
     float *t32, *x32, *n32 = nullptr;
     RET(wsalloc(h, (size_t)M * 1024, &f16in));
@@ -1376,7 +1409,7 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     RET(wsalloc(h, (size_t)M * 512, &n16));
     if (parts & 8) RET(wsalloc(h, (size_t)M * 512, &n32));
     if (parts & 1) {
-        RET(jegal_input32(h, feats, M, T, t32, x32));
+        RET(jegal_input32(h, feats, M, T, t32, x32, ends_x3));
     } else {
         RET(timed(h, JG_ST_MISC, [&] { return LAUNCH(h, launch_cast_f32_f16, feats, f16in, (long)M * 1024, h->stream); }));
         Epi e; e.out32 = t32;
@@ -1386,7 +1419,7 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
         RET(gemm(h, JG_ST_GEMM, t16, 512, M, h->ip3, p));
     }
     RET(annotated_encoder(h, h->rgb_layers, 6, h->rgb_norm, x32, n16, mask, B, T, 512, 2048, parts, n32));
-    if (parts & 8) return jegal_tail32(h, n32, M, align, out);
+    if (parts & 8) return jegal_tail32(h, n32, M, align, out, ends_x3);
     if (!align) {
         Epi o; o.out32 = out;
         return gemm(h, JG_ST_GEMM, n16, 512, M, h->op_rgb, o);
@@ -1973,6 +2006,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
+    if (!std::strcmp(name, "rc_layers")) { h->rc_layers = value & 15; return JG_OK; }
     if (!std::strcmp(name, "jegal_fp32_ends")) { h->jegal_fp32_ends = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv_round_diffuse")) {
         if (h->gs_ready || h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "set conv_round_diffuse before jg_finalize_weights");

@@ -40,3 +40,24 @@ hipError_t launch_maxpool3x3s2_32(const float* in, float* out, int N, int H, int
 hipError_t launch_group_mean32(const float* in, int groups, int L, int D, float* out, hipStream_t s);
 // rows h >= len_b of clip b of an NHWC fp32 tensor [B][H][row_elems] set to zero, len_b = valid[b] halved ((len - 1) / 2 + 1) `halvings` times
 hipError_t launch_zero_tail32(float* x, const int* valid, int halvings, int B, int H, long row_elems, hipStream_t s);
+
+// Split-operand GEMM on the fp16 matrix cores (the two ends of the JEGAL gesture branch in the fp16 modes, option jegal_fp32_ends):
+//   out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] + res[m % res_mod][n] ),   A fp32, W = Wh + Wl (fp16 pair), out fp32,
+// with A split into hi + lo fp16 IN THE LOADER and three MFMAs per fragment pair (Ah Wh + Ah Wl + Al Wh; the dropped Al Wl term is 2^-22
+// of the product): fp32-grade products at 3/16 of the cost of the fp32 MFMA.  K % 64 == 0, N % 128 == 0, lda % 4 == 0.
+struct GemmX3Args {
+    const float* A;
+    long lda;
+    const f16* Wh;
+    const f16* Wl;
+    long ldw;
+    int M, N, K;
+    const float* bias;
+    const float* res;
+    long ldr;
+    int res_mod;
+    float* out;
+    long ldc;
+    int relu;
+};
+hipError_t launch_gemm_x3(const GemmX3Args& a, hipStream_t s);

@@ -228,6 +228,121 @@ __global__ __launch_bounds__(256) void attention32_kernel(const float* __restric
     for (int d = 0; d < DK; ++d) op[d] = o[d] * inv;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split-operand GEMM (GemmX3Args, audit32.h).  Tile 64 (m) x 128 (n) x 64 (k), 4 waves side by side along n (each 64 m x 32 n = 4 x 2
+// MFMA tiles of v_mfma_f32_16x16x32_f16), operands through LDS in 128-B rows with the XOR swizzle of gemm.hip; the fp32 activation tile
+// is loaded as float4s, split into hi / lo fp16 in registers and written as two LDS tiles; register-staged prefetch of the next k-tile.
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args a) {
+    constexpr int BM = 64, BN = 128;
+    __shared__ __attribute__((aligned(16))) char sXh[BM * 128];
+    __shared__ __attribute__((aligned(16))) char sXl[BM * 128];
+    __shared__ __attribute__((aligned(16))) char sWh[BN * 128];
+    __shared__ __attribute__((aligned(16))) char sWl[BN * 128];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n_tiles = a.N / BN;
+    const int n0 = (blockIdx.x % n_tiles) * BN;
+    const int m0 = (int)(blockIdx.x / n_tiles) * BM;
+    // A loader: row t >> 2, 16 consecutive k at (t & 3) * 16 = the 16-B chunks 2 (t & 3) and 2 (t & 3) + 1 of the row's hi / lo tiles
+    const int xr = t >> 2, xc = (t & 3) * 2;
+    const bool xok = m0 + xr < a.M;
+    const float* xp = a.A + (long)(xok ? m0 + xr : 0) * a.lda + (t & 3) * 16;
+    // W loader: row t >> 1, 32 consecutive k at (t & 1) * 32 = chunks 4 (t & 1) .. + 3
+    const int wr = t >> 1, wc = (t & 1) * 4;
+    const f16* whp = a.Wh + (long)(n0 + wr) * a.ldw + (t & 1) * 32;
+    const f16* wlp = a.Wl + (long)(n0 + wr) * a.ldw + (t & 1) * 32;
+
+    f32x4 xv[4];
+    uint4 whv[4], wlv[4];
+    auto load_tile = [&](int kt) {
+        const int k = kt * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xv[q] = xok ? *reinterpret_cast<const f32x4*>(xp + k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            whv[q] = *reinterpret_cast<const uint4*>(whp + k + 8 * q);
+            wlv[q] = *reinterpret_cast<const uint4*>(wlp + k + 8 * q);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = xv[hq * 2 + (e >> 2)][e & 3];
+                const f16 hv = (f16)v;
+                hi[e] = hv;
+                lo[e] = (f16)(v - (float)hv);
+            }
+            const int off = xr * 128 + (((xc + hq) ^ ((xr >> 1) & 7)) << 4);
+            *reinterpret_cast<f16x8*>(sXh + off) = hi;
+            *reinterpret_cast<f16x8*>(sXl + off) = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = wr * 128 + (((wc + q) ^ ((wr >> 1) & 7)) << 4);
+            *reinterpret_cast<uint4*>(sWh + off) = whv[q];
+            *reinterpret_cast<uint4*>(sWl + off) = wlv[q];
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / 64;
+    const int frow = lane & 15, fq = lane >> 4, fsw = (frow >> 1) & 7;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int choff = ((kk * 4 + fq) ^ fsw) << 4;
+            f16x8 wf[2], wl[2], xh[4], xl[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave * 32 + i * 16 + frow;
+                wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
+                wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 16 + frow;
+                xh[j] = *reinterpret_cast<const f16x8*>(sXh + row * 128 + choff);
+                xl[j] = *reinterpret_cast<const f16x8*>(sXl + row * 128 + choff);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // smallest terms first: the two cross terms, then the main product
+                    acc[i][j] = JG_MFMA_16x16x32(wl[i], xh[j], acc[i][j]);
+                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);
+                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xh[j], acc[i][j]);
+                }
+        }
+    }
+    // lane holds D[n = 4 fq + r][m = frow] of each 16 x 16 tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wave * 32 + i * 16 + fq * 4;
+        const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + j * 16 + frow;
+            if (m >= a.M) continue;
+            f32x4 v = acc[i][j] + bi;
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (long)(a.res_mod ? m % a.res_mod : m) * a.ldr + n);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.out + (long)m * a.ldc + n) = v;
+        }
+    }
+}
+
 template <typename SRC>
 __global__ void stack_frames32_kernel(const SRC* __restrict__ src, long sb, long st, long sh, long sw, long sc, int B, int T, int pad, int H, int W,
                                       float* __restrict__ dst) {
@@ -371,5 +486,15 @@ hipError_t launch_zero_tail32(float* x, const int* valid, int halvings, int B, i
     if (B <= 0 || H <= 0 || !valid) return hipSuccess;
     if (row_elems % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(zero_tail32_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, x, valid, halvings, H, (int)(row_elems / 4));
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (!a.A || !a.Wh || !a.Wl || !a.out || a.K <= 0 || a.K % 64 || a.N <= 0 || a.N % 128 || (a.lda & 3) || (a.ldw & 7) || (a.ldc & 3) || (a.res && (a.ldr & 3)) ||
+        ((uintptr_t)a.A & 15))
+        return hipErrorInvalidValue;
+    const long tiles = (long)((a.M + 63) / 64) * (a.N / 128);
+    hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -12,8 +12,16 @@ relative perturbation (1e-6) of the conv stack's output moves the final embeddin
 branch.  Gaussian draw: 0.10, heavy: 0.08, x 2: 0.28, x 4: 1.7 (T = 40 figures) -- the x 4 net amplifies every upstream rounding 17 times
 more than the net the 1e-3 contract was written for, in ANY implementation (with random features at the JEGAL branch's input that
 branch alone amplifies x 24: a 1e-4 input perturbation moves its fp64 output by 2.3e-3).  No 16-bit operand format (fp16: 2^-11 per
-operand; the reference's own CUDA autocast path is the same arithmetic) can hold 1e-3 there.  Rule: a family whose factor is within
-3 x the Gaussian draw's must meet 1e-3 in the mode the drivers select; beyond that it is REPORTED and held to 1e-3 x factor ratio / 3.
+operand; the reference's own CUDA autocast path is the same arithmetic) can hold 1e-3 there.
+
+Round 6 (VERDICT r5 item 2 / ADVICE r5): the widened bound (1e-3 x factor ratio / 3, which let a 33 % error pass) is gone.  Every family also runs
+in the fp32 AUDIT mode (JG_PREC_FP32: exact-fp32 MFMAs, fp32 activations), which must reproduce the fp32 oracle on EVERY family, `sharp`
+included (the bound is 2e-5 for networks in the regime and scales with the measured fp64 conditioning beyond it -- fp32 summation order
+is amplified like any other perturbation; the measured values are printed).  Rule for the fp16 modes: a family whose conditioning is
+within 3 x the Gaussian draw's must meet the plain 1e-3 in the mode the drivers select.  Beyond that no 16-bit operand format can
+(reported), and the test asserts what a user WITHOUT an oracle would see: the distance between the default mode and the audit mode --
+what `python -m jegal_amd.drivers inference_embs ... --audit` prints -- equals the true error to the audit mode's own accuracy, so the
+driver's WARNING fires exactly when the contract is broken.
 """
 import json
 import os
@@ -27,6 +35,7 @@ from jegal_amd import synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+AUD_TOL = 2e-5
 T = 150
 FAMILIES = [("gauss", 0), ("gauss", 1), ("gauss", 2), ("heavy", 0), ("sharp2", 0), ("sharp", 0)]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -84,10 +93,8 @@ def gauss_amplification(frames0):
 
 def gesture_modes():
     import jegal_amd._lib as L
-    modes = [("bc_builtin", L.PREC_FP16_BC, None), ("bc_own_clips", L.PREC_FP16_BC, "own"), ("w2", L.PREC_FP16_W2, None)]
-    if hasattr(L, "PREC_FP16_RC"):
-        modes.append(("rc", L.PREC_FP16_RC, None))
-    return modes
+    return [("bc_builtin", L.PREC_FP16_BC, None), ("bc_own_clips", L.PREC_FP16_BC, "own"), ("w2", L.PREC_FP16_W2, None), ("rc", L.PREC_FP16_RC, None),
+            ("fp32_audit", L.PREC_FP32, None)]
 
 
 @pytest.mark.parametrize("family", FAMILIES, ids=fam_id)
@@ -119,11 +126,13 @@ def test_gesture_and_content_across_weight_families(family):
     assert np.isfinite(cref).all() and all(np.isfinite(r[1]).all() for r in refs)
     amp, amp_ref = amplification(gt, jt, conv0), gauss_amplification(frames[0])
     ratio = amp / amp_ref
-    bound = TOL if ratio <= 3.0 else TOL * ratio / 3.0
-    print(f"\n[{fam_id(family)}] conditioning (fp64, d embedding / d conv features): {amp:.3f} = {ratio:.1f} x the Gaussian draw's -> bound {bound:.2e}", end="")
-    record(f"{fam_id(family)}/conditioning", amplification=amp, ratio_to_gauss=ratio, bound=bound)
+    in_regime = ratio <= 3.0
+    aud_bound = AUD_TOL * max(1.0, ratio / 3.0)
+    print(f"\n[{fam_id(family)}] conditioning (fp64, d embedding / d conv features): {amp:.3f} = {ratio:.1f} x the Gaussian draw's -> "
+          f"{'in the regime of the 1e-3 contract' if in_regime else 'OUTSIDE the regime of any 16-bit operand format: fp16 modes reported, audit mode asserted'}", end="")
+    record(f"{fam_id(family)}/conditioning", amplification=amp, ratio_to_gauss=ratio, in_regime=in_regime, audit_bound=aud_bound)
     dev = torch.from_numpy(frames).cuda()
-    worst = {}
+    worst, outs = {}, {}
     for mname, mode, cal in gesture_modes():
         e = Engine(0, precision=mode)
         try:
@@ -145,10 +154,23 @@ def test_gesture_and_content_across_weight_families(family):
         print(f"\n[{fam_id(family)}] {mname:13s} gesture rel-L2 {rg:.3e} max-abs {mg:.3e} | GestSync feats {rf:.3e} | content rel-L2 {rc:.3e} max-abs {mc:.3e}", end="")
         record(f"{fam_id(family)}/{mname}", gesture_rel=rg, gesture_maxabs=mg, feats_rel=rf, content_rel=rc, content_maxabs=mc)
         worst[mname] = max(rg, mg, rc, mc)
-    # the contract: the mode a driver selects for a checkpoint it has never seen (drivers.pick_precision) holds 1e-3 on every family
+        outs[mname] = (emb, cont)
+    # (1) the audit mode reproduces the fp32 oracle on every family
+    assert worst["fp32_audit"] < aud_bound, (family, worst["fp32_audit"], aud_bound)
+    # (2) the contract: the mode a driver selects for a checkpoint it has never seen (drivers.pick_precision) holds the plain 1e-3 on every
+    #     family whose conditioning is in the regime
     from jegal_amd.drivers import REAL_CHECKPOINT_PRECISION
-    sel = {L.PREC_FP16_W2: "w2", getattr(L, "PREC_FP16_RC", -1): "rc"}[REAL_CHECKPOINT_PRECISION]
-    assert worst[sel] < bound, (family, sel, worst)
+    sel = {L.PREC_FP16_W2: "w2", L.PREC_FP16_RC: "rc"}[REAL_CHECKPOINT_PRECISION]
+    if in_regime:
+        assert worst[sel] < TOL, (family, sel, worst)
+    # (3) what `--audit` reports (default mode vs audit mode, no oracle) is the true error: the driver warns exactly when the contract breaks
+    seen = max(max(rel(outs[sel][0][b], outs["fp32_audit"][0][b]) for b in range(B)), rel(outs[sel][1], outs["fp32_audit"][1]))
+    true = max(max(rel(outs[sel][0][b], refs[b][1]) for b in range(B)), rel(outs[sel][1], cref))
+    print(f"\n[{fam_id(family)}] --audit would report {seen:.3e} for the {sel} mode; true error vs the oracle {true:.3e}", end="")
+    record(f"{fam_id(family)}/audit_report", reported=seen, true=true)
+    assert abs(seen - true) < max(5e-5, 2 * aud_bound), (family, seen, true)
+    if not in_regime:
+        assert (seen >= TOL) == (true >= TOL), (family, seen, true)
 
 
 @pytest.mark.parametrize("family", FAMILIES, ids=fam_id)
@@ -174,13 +196,16 @@ def test_xlmr_12_layers_across_weight_families(family):
         _GAUSS_XLMR_AMP.append(xlmr_amp(synth.xlmr_state_dict(layers=12)))
     amp = xlmr_amp(sd, ref)
     ratio = amp / _GAUSS_XLMR_AMP[0]
-    bound = TOL if ratio <= 3.0 else TOL * ratio / 3.0
-    print(f"\n[{fam_id(family)}] xlmr conditioning (d out / d embeddings): {amp:.2f} = {ratio:.1f} x the Gaussian draw's -> bound {bound:.2e}", end="")
-    record(f"{fam_id(family)}/xlmr_conditioning", amplification=amp, ratio_to_gauss=ratio, bound=bound)
+    in_regime = ratio <= 3.0
+    aud_bound = AUD_TOL * max(1.0, ratio / 3.0)
+    print(f"\n[{fam_id(family)}] xlmr conditioning (d out / d embeddings): {amp:.2f} = {ratio:.1f} x the Gaussian draw's -> "
+          f"{'in regime' if in_regime else 'OUTSIDE the regime: fp16 reported, audit asserted'}", end="")
+    record(f"{fam_id(family)}/xlmr_conditioning", amplification=amp, ratio_to_gauss=ratio, in_regime=in_regime, audit_bound=aud_bound)
     ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
-    errs = {}
-    for mname in ("hi_lo", "bc_builtin_ids", "bc_own_ids"):
-        e = Engine(0)
+    errs, outs = {}, {}
+    import jegal_amd._lib as L
+    for mname in ("hi_lo", "bc_builtin_ids", "bc_own_ids", "fp32_audit"):
+        e = Engine(0, precision=L.PREC_FP32 if mname == "fp32_audit" else None)
         try:
             x = XLMRoberta(engine=e).load_state_dict(sd)
             if mname == "bc_builtin_ids":
@@ -192,7 +217,14 @@ def test_xlmr_12_layers_across_weight_families(family):
             e.close()
         assert torch.isfinite(out).all()
         errs[mname] = rel(out[m].numpy(), ref[m].numpy())
+        outs[mname] = out[m].numpy()
         mx = float((out[m] - ref[m]).abs().max())
         print(f"\n[{fam_id(family)}] xlmr {mname:15s} rel-L2 {errs[mname]:.3e} max-abs {mx:.3e}", end="")
         record(f"{fam_id(family)}/xlmr_{mname}", rel=errs[mname], maxabs=mx)
-    assert errs["hi_lo"] < bound, (family, errs)          # the calibration-free default
+    assert errs["fp32_audit"] < aud_bound, (family, errs["fp32_audit"], aud_bound)
+    if in_regime:
+        assert errs["hi_lo"] < TOL, (family, errs)          # the calibration-free default
+    seen = rel(outs["hi_lo"], outs["fp32_audit"])
+    print(f"\n[{fam_id(family)}] xlmr: an audit of the default mode would report {seen:.3e}; true error {errs['hi_lo']:.3e}", end="")
+    record(f"{fam_id(family)}/xlmr_audit_report", reported=seen, true=errs["hi_lo"])
+    assert abs(seen - errs["hi_lo"]) < max(5e-5, 2 * aud_bound), (family, seen, errs)

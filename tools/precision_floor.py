@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--clips", type=int, default=2)
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--opts", default="", help="extra engine options for the RC rows, e.g. stream_fp16=0")
+    ap.add_argument("--rc-ablate", action="store_true", help="rows with the run-time correction switched off per Linear type")
     ap.add_argument("--quick", action="store_true", help="only the four rows of round 6's measures")
     args = ap.parse_args()
     T, B = args.frames, args.clips
@@ -87,6 +88,11 @@ def main():
         run("rc ends=1 diffuse=0", L.PREC_FP16_RC, opts=[("conv_round_diffuse", 0)])
         run("rc ends=0 diffuse=1", L.PREC_FP16_RC, opts=[("jegal_fp32_ends", 0)])
         run("rc default", L.PREC_FP16_RC)
+        if args.rc_ablate:
+            # which Linear types of the GestSync transformer need the run-time correction?  (option rc_layers: 1 qkv, 2 out_proj, 4 linear1 +
+            # ff_vid.0, 8 linear2; the others run single fp16 without a correction -- measurement only)
+            for m in (0, 1, 2, 4, 8, 14, 13, 11, 7, 12, 10, 6):
+                run(f"rc rc_layers={m}", L.PREC_FP16_RC, opts=[("rc_layers", m)])
         if args.quick:
             table[fam] = rows
             continue
