@@ -238,6 +238,23 @@ int jg_spot(jg_handle* h, const float* gesture, const float* content, const int3
 /* evaluate_asd.py:43-51,94-100: pred (n,3) = argmax over the first 2/4/6 candidates */
 int jg_asd(jg_handle* h, const float* query, const float* cand, const int32_t* c_offsets, int n, int D, float temp, int32_t* pred);
 
+/* ---- multi-GPU exchange.  The reference is single-process (its only parallelism is the --rank / --nshard file-list split of
+ *      preprocess/extract_gestsync_feats.py:366-370); clips shard with no data-path collective, and the ONE exchange of the path is the
+ *      gallery all-gather in front of the retrieval similarity matrix (+ a counter all-reduce for R@K / spotting / ASD).  These entries give a
+ *      consumer of the C ABI that exchange on RCCL over xGMI without PyTorch: one communicator per handle (= per rank = per GPU), collectives
+ *      enqueued on the handle's stream.  librccl.so is bound with dlopen at the first call (no link-time dependency).  jegal_amd/dist.py does
+ *      the same through torch.distributed (backend "nccl" = RCCL). ---------------------------------------------------------------------- */
+#define JG_COMM_ID_BYTES 128
+/* rank 0: ncclGetUniqueId into a 128-byte host buffer, to be handed to every rank by the launcher (a file, MPI, a socket, torchrun's store) */
+int jg_comm_get_unique_id(char* id128_host);
+/* collective over all ranks: ncclCommInitRank on the handle's device */
+int jg_comm_init(jg_handle* h, const char* id128_host, int rank, int world);
+int jg_comm_destroy(jg_handle* h);
+/* recv (world * bytes_per_rank bytes, device) = the ranks' send buffers (bytes_per_rank bytes each, device) in rank order */
+int jg_allgather(jg_handle* h, const void* send, void* recv, int64_t bytes_per_rank);
+/* in place sum over the ranks of n int64 counters (device) */
+int jg_allreduce_sum_i64(jg_handle* h, int64_t* buf, int n);
+
 /* ---- profiling: HIP-event timing per stage on the handle's stream -------------------------- */
 enum { JG_ST_STACK = 0, JG_ST_CONV1, JG_ST_POOL, JG_ST_CONV, JG_ST_GEMM, JG_ST_ATTN, JG_ST_NORM, JG_ST_MISC, JG_ST_CONV1_AUX, JG_ST_COUNT };
 /* on: 0 = off, 1 = every launch is bracketed by two events, 2 + stage = only the launches of that stage are (the other

@@ -59,6 +59,11 @@ _SIGS = {
     "jg_sim_rank": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "jg_spot": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _P],
     "jg_asd": [_P, _P, _P, _P, _I, _I, ctypes.c_float, _P],
+    "jg_comm_get_unique_id": [ctypes.c_char_p],
+    "jg_comm_init": [_P, ctypes.c_char_p, _I, _I],
+    "jg_comm_destroy": [_P],
+    "jg_allgather": [_P, _P, _P, ctypes.c_int64],
+    "jg_allreduce_sum_i64": [_P, _P, _I],
     "jg_profile_enable": [_P, _I],
     "jg_profile_get": [_P, _I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)],
     "jg_profile_reset": [_P],
@@ -492,6 +497,39 @@ class Engine:
         return pred
 
     # ---- profiling
+    # ---- multi-GPU exchange on RCCL through the C ABI (jegal_amd/dist.py uses torch.distributed for the same exchange)
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: a 128-byte RCCL id for the launcher to hand to every rank."""
+        buf = ctypes.create_string_buffer(128)
+        rc = load_library().jg_comm_get_unique_id(buf)
+        if rc != 0:
+            raise JegalError(f"jg_comm_get_unique_id failed with {rc} (librccl.so not loadable?)")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.jg_comm_init(self.h, bytes(unique_id), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        self._ck(self.lib.jg_comm_destroy(self.h))
+        self.comm_world = 1
+
+    def allgather(self, x):
+        """(n, ...) per rank -> (world * n, ...) in rank order (ncclAllGather on the engine's stream)."""
+        self._bind_stream()
+        x = x.to(self.device).contiguous()
+        out = torch.empty((getattr(self, "comm_world", 1) * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=self.device)
+        self._ck(self.lib.jg_allgather(self.h, _ptr(x), _ptr(out), x.numel() * x.element_size()))
+        return out
+
+    def allreduce_sum_i64(self, counts):
+        self._bind_stream()
+        t = torch.as_tensor(counts, dtype=torch.int64).to(self.device).contiguous().clone()
+        self._ck(self.lib.jg_allreduce_sum_i64(self.h, _ptr(t), t.numel()))
+        return t
+
     def profile(self, on, only=None):
         """on: bracket every launch with HIP events; only="conv1": bracket just that stage (the rest of the step runs back to back)."""
         self._ck(self.lib.jg_profile_enable(self.h, 2 + STAGES.index(only) if (on and only) else int(bool(on))))

@@ -7,6 +7,8 @@
 #include "../../include/jegal_hip.h"
 #include "audit32.h"
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +105,39 @@ struct Arena {          // stream-ordered bump allocator over persistent chunks
 };
 
 struct ProfRec { int stage; hipEvent_t e0, e1; };
+
+// ---- RCCL, bound at run time (jg_comm_* / jg_allgather / jg_allreduce_sum_i64): the library has no link-time dependency on librccl -- a
+// single-GPU consumer never loads it; inside a PyTorch process dlopen returns the copy torch already mapped (same SONAME).
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void* id) = nullptr;
+    void* CommInitRank = nullptr;      // takes ncclUniqueId BY VALUE: cast at the call site (jg_comm_init)
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+struct NcclId { char internal[128]; };          // layout of ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+inline Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        x.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclGetUniqueId"));
+        x.CommInitRank = dlsym(x.lib, "ncclCommInitRank");
+        x.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(x.lib, "ncclAllGather"));
+        x.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(x.lib, "ncclAllReduce"));
+        x.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(x.lib, "ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.AllGather && x.AllReduce && x.CommDestroy;
+        return x;
+    }();
+    return r;
+}
 
 }  // namespace
 
@@ -201,6 +236,8 @@ struct jg_handle {
     // sub-layers, 4 feed-forward sub-layers, 8 final norm + output / align projections run on the fp32 kernels (the residual stream
     // between them is fp32 in every mode)
     int audit_jegal_parts = 0;
+    void* comm = nullptr;          // ncclComm_t of this rank (jg_comm_init) or nullptr
+    int comm_rank = 0, comm_world = 1;
     int xl_lanes = 2;              // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams
 };
 
@@ -1941,6 +1978,7 @@ int jg_destroy(jg_handle* h) {
         for (int l = 0; l < jg_handle::MAX_LANES; ++l) { h->lane_ws[l].release(); if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]); }
         for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) (void)hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
+        if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     }
     delete h;
@@ -2422,6 +2460,58 @@ int jg_asd(jg_handle* h, const float* q, const float* cand, const int32_t* coff,
     ENTER(h);
     if (!q || !cand || !coff || !pred) JG_FAIL(h, JG_ERR_ARG, "null buffer");
     return timed(h, JG_ST_MISC, [&] { return launch_asd(q, cand, coff, n, D, temp, pred, h->stream); });
+}
+
+// ---- multi-GPU exchange on RCCL: one communicator per handle = per rank = per GPU
+int jg_comm_get_unique_id(char* id128_host) {
+    if (!id128_host) return JG_ERR_ARG;
+    if (!rccl().ok) return JG_ERR_STATE;
+    NcclId id;
+    if (rccl().GetUniqueId(&id) != 0) return JG_ERR_HIP;
+    std::memcpy(id128_host, id.internal, sizeof(id.internal));
+    return JG_OK;
+}
+
+int jg_comm_init(jg_handle* h, const char* id128_host, int rank, int world) {
+    ENTER(h);
+    if (!id128_host || world < 1 || rank < 0 || rank >= world) JG_FAIL(h, JG_ERR_ARG, "bad communicator arguments");
+    if (!rccl().ok) JG_FAIL(h, JG_ERR_STATE, "librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (h->comm) { (void)rccl().CommDestroy(h->comm); h->comm = nullptr; }
+    NcclId id;
+    std::memcpy(id.internal, id128_host, sizeof(id.internal));
+    typedef int (*init_t)(void**, int, NcclId, int);          // ncclCommInitRank(ncclComm_t*, int nranks, ncclUniqueId commId, int rank)
+    const int rc = reinterpret_cast<init_t>(rccl().CommInitRank)(&h->comm, world, id, rank);
+    if (rc != 0) { h->comm = nullptr; JG_FAIL(h, JG_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"); }
+    h->comm_rank = rank; h->comm_world = world;
+    return JG_OK;
+}
+
+int jg_comm_destroy(jg_handle* h) {
+    ENTER(h);
+    if (h->comm && rccl().ok) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        (void)rccl().CommDestroy(h->comm);
+    }
+    h->comm = nullptr; h->comm_rank = 0; h->comm_world = 1;
+    return JG_OK;
+}
+
+int jg_allgather(jg_handle* h, const void* send, void* recv, int64_t bytes_per_rank) {
+    ENTER(h);
+    if (!send || !recv || bytes_per_rank < 0) JG_FAIL(h, JG_ERR_ARG, "bad allgather arguments");
+    if (!h->comm) JG_FAIL(h, JG_ERR_STATE, "jg_allgather before jg_comm_init");
+    const int rc = rccl().AllGather(send, recv, (size_t)bytes_per_rank, /* ncclInt8 */ 0, h->comm, h->stream);
+    if (rc != 0) JG_FAIL(h, JG_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+    return JG_OK;
+}
+
+int jg_allreduce_sum_i64(jg_handle* h, int64_t* buf, int n) {
+    ENTER(h);
+    if (!buf || n < 0) JG_FAIL(h, JG_ERR_ARG, "bad allreduce arguments");
+    if (!h->comm) JG_FAIL(h, JG_ERR_STATE, "jg_allreduce_sum_i64 before jg_comm_init");
+    const int rc = rccl().AllReduce(buf, buf, (size_t)n, /* ncclInt64 */ 4, /* ncclSum */ 0, h->comm, h->stream);
+    if (rc != 0) JG_FAIL(h, JG_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+    return JG_OK;
 }
 
 int jg_profile_enable(jg_handle* h, int on) {
