@@ -44,7 +44,7 @@ hipError_t launch_zero_tail32(float* x, const int* valid, int halvings, int B, i
 // Split-operand GEMM on the fp16 matrix cores (the two ends of the JEGAL gesture branch in the fp16 modes, option jegal_fp32_ends):
 //   out[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] + res[m % res_mod][n] ),   A fp32, W = Wh + Wl (fp16 pair), out fp32,
 // with A split into hi + lo fp16 IN THE LOADER and three MFMAs per fragment pair (Ah Wh + Ah Wl + Al Wh; the dropped Al Wl term is 2^-22
-// of the product): fp32-grade products at 3/16 of the cost of the fp32 MFMA.  K % 64 == 0, N % 128 == 0, lda % 4 == 0.
+// of the product): fp32-grade products at 3/16 of the cost of the fp32 MFMA.  K % 256 == 0, N % 128 == 0, lda % 4 == 0.
 struct GemmX3Args {
     const float* A;
     long lda;

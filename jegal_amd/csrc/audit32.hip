@@ -1,5 +1,6 @@
 // fp32 audit kernels (gfx950): see audit32.h.  Exact fp32 products on v_mfma_f32_32x32x2_f32, fp32 everywhere else.
 #include "audit32.h"
+#include <type_traits>
 
 namespace {
 
@@ -230,11 +231,14 @@ __global__ __launch_bounds__(256) void attention32_kernel(const float* __restric
 
 
 // ---------------------------------------------------------------------------------------------
-// Split-operand GEMM (GemmX3Args, audit32.h).  Tile 64 (m) x 128 (n) x 64 (k), 4 waves side by side along n (each 64 m x 32 n = 4 x 2
-// MFMA tiles of v_mfma_f32_16x16x32_f16), operands through LDS in 128-B rows with the XOR swizzle of gemm.hip; the fp32 activation tile
-// is loaded as float4s, split into hi / lo fp16 in registers and written as two LDS tiles; register-staged prefetch of the next k-tile.
+// Split-operand GEMM (GemmX3Args, audit32.h).  These launches are small (M = B * T rows of the JEGAL branch) and LATENCY-bound: a first
+// version with 64 x 128 tiles and one k-tile of prefetch took 63 us for 4800 x 512 x 512 (3.8 us per k-tile: one exposed memory round
+// trip each, ~1 workgroup per CU).  Hence: tile 32 (m) x 128 (n) x 64 (k) for 4 x the workgroups, and a ring of FOUR register stages --
+// the loads of k-tiles kt + 1 .. kt + 3 are in flight while k-tile kt is split, staged and multiplied.  4 waves side by side along n
+// (each 32 m x 32 n = 2 x 2 tiles of v_mfma_f32_16x16x32_f16), operands through LDS in 128-B rows with the XOR swizzle of gemm.hip.
+// K % 256 == 0 (the k loop is unrolled by the ring depth).
 __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args a) {
-    constexpr int BM = 64, BN = 128;
+    constexpr int BM = 32, BN = 128, DEPTH = 4;
     __shared__ __attribute__((aligned(16))) char sXh[BM * 128];
     __shared__ __attribute__((aligned(16))) char sXl[BM * 128];
     __shared__ __attribute__((aligned(16))) char sWh[BN * 128];
@@ -243,96 +247,96 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args a) {
     const int n_tiles = a.N / BN;
     const int n0 = (blockIdx.x % n_tiles) * BN;
     const int m0 = (int)(blockIdx.x / n_tiles) * BM;
-    // A loader: row t >> 2, 16 consecutive k at (t & 3) * 16 = the 16-B chunks 2 (t & 3) and 2 (t & 3) + 1 of the row's hi / lo tiles
-    const int xr = t >> 2, xc = (t & 3) * 2;
+    // A loader: row t >> 3, the 8 consecutive k of 16-B chunk t & 7 (two float4)
+    const int xr = t >> 3, xc = t & 7;
     const bool xok = m0 + xr < a.M;
-    const float* xp = a.A + (long)(xok ? m0 + xr : 0) * a.lda + (t & 3) * 16;
-    // W loader: row t >> 1, 32 consecutive k at (t & 1) * 32 = chunks 4 (t & 1) .. + 3
+    const float* xp = a.A + (long)(xok ? m0 + xr : 0) * a.lda + xc * 8;
+    // W loader: row t >> 1, chunks 4 (t & 1) .. + 3
     const int wr = t >> 1, wc = (t & 1) * 4;
     const f16* whp = a.Wh + (long)(n0 + wr) * a.ldw + (t & 1) * 32;
     const f16* wlp = a.Wl + (long)(n0 + wr) * a.ldw + (t & 1) * 32;
 
-    f32x4 xv[4];
-    uint4 whv[4], wlv[4];
-    auto load_tile = [&](int kt) {
-        const int k = kt * 64;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xv[q] = xok ? *reinterpret_cast<const f32x4*>(xp + k + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            whv[q] = *reinterpret_cast<const uint4*>(whp + k + 8 * q);
-            wlv[q] = *reinterpret_cast<const uint4*>(wlp + k + 8 * q);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int hq = 0; hq < 2; ++hq) {
-            f16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = xv[hq * 2 + (e >> 2)][e & 3];
-                const f16 hv = (f16)v;
-                hi[e] = hv;
-                lo[e] = (f16)(v - (float)hv);
-            }
-            const int off = xr * 128 + (((xc + hq) ^ ((xr >> 1) & 7)) << 4);
-            *reinterpret_cast<f16x8*>(sXh + off) = hi;
-            *reinterpret_cast<f16x8*>(sXl + off) = lo;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int off = wr * 128 + (((wc + q) ^ ((wr >> 1) & 7)) << 4);
-            *reinterpret_cast<uint4*>(sWh + off) = whv[q];
-            *reinterpret_cast<uint4*>(sWl + off) = wlv[q];
-        }
-    };
-
-    f32x4 acc[2][4];
+    f32x4 xv[DEPTH][2];
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t whv[DEPTH][4], wlv[DEPTH][4];
+    static_assert(DEPTH == 4, "the k loop below is written out for a ring of four stages");
+    f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = a.K / 64;
     const int frow = lane & 15, fq = lane >> 4, fsw = (frow >> 1) & 7;
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int choff = ((kk * 4 + fq) ^ fsw) << 4;
-            f16x8 wf[2], wl[2], xh[4], xl[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wave * 32 + i * 16 + frow;
-                wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);
-                wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = j * 16 + frow;
-                xh[j] = *reinterpret_cast<const f16x8*>(sXh + row * 128 + choff);
-                xl[j] = *reinterpret_cast<const f16x8*>(sXl + row * 128 + choff);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // smallest terms first: the two cross terms, then the main product
-                    acc[i][j] = JG_MFMA_16x16x32(wl[i], xh[j], acc[i][j]);
-                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);
-                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xh[j], acc[i][j]);
-                }
-        }
+    // (written as macros with literal stage indices: through lambdas, or with run-time indices, hipcc kept the ring in scratch memory)
+#define X3_LOAD(ST, KT)                                                                                          \
+    {                                                                                                            \
+        const int k_ = (KT) * 64;                                                                                \
+        xv[ST][0] = xok ? *reinterpret_cast<const f32x4*>(xp + k_) : f32x4{0.f, 0.f, 0.f, 0.f};                  \
+        xv[ST][1] = xok ? *reinterpret_cast<const f32x4*>(xp + k_ + 4) : f32x4{0.f, 0.f, 0.f, 0.f};              \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
+            whv[ST][q] = *reinterpret_cast<const u32x4_t*>(whp + k_ + 8 * q);                                   \
+            wlv[ST][q] = *reinterpret_cast<const u32x4_t*>(wlp + k_ + 8 * q);                                   \
+        }                                                                                                        \
     }
+#define X3_TILE(ST, KT)                                                                                          \
+    {                                                                                                            \
+        if ((KT) + DEPTH - 1 < nk) X3_LOAD(((ST) + DEPTH - 1) % DEPTH, (KT) + DEPTH - 1)                          \
+        __syncthreads();                                                                                         \
+        {                                                                                                        \
+            const f32x4 x0_ = xv[ST][0], x1_ = xv[ST][1];                                                        \
+            const f16x8 hi_ = {(f16)x0_.x, (f16)x0_.y, (f16)x0_.z, (f16)x0_.w, (f16)x1_.x, (f16)x1_.y, (f16)x1_.z, (f16)x1_.w};          \
+            const f16x8 lo_ = {(f16)(x0_.x - (float)hi_[0]), (f16)(x0_.y - (float)hi_[1]), (f16)(x0_.z - (float)hi_[2]), (f16)(x0_.w - (float)hi_[3]),   \
+                               (f16)(x1_.x - (float)hi_[4]), (f16)(x1_.y - (float)hi_[5]), (f16)(x1_.z - (float)hi_[6]), (f16)(x1_.w - (float)hi_[7])};  \
+            const int off_ = xr * 128 + ((xc ^ ((xr >> 1) & 7)) << 4);                                           \
+            *reinterpret_cast<f16x8*>(sXh + off_) = hi_;                                                         \
+            *reinterpret_cast<f16x8*>(sXl + off_) = lo_;                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                const int o2_ = wr * 128 + (((wc + q) ^ ((wr >> 1) & 7)) << 4);                                  \
+                *reinterpret_cast<u32x4_t*>(sWh + o2_) = whv[ST][q];                                            \
+                *reinterpret_cast<u32x4_t*>(sWl + o2_) = wlv[ST][q];                                            \
+            }                                                                                                    \
+        }                                                                                                        \
+        __syncthreads();                                                                                         \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                       \
+            const int choff = ((kk * 4 + fq) ^ fsw) << 4;                                                        \
+            f16x8 wf[2], wl[2], xh[2], xl[2];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+                const int row = wave * 32 + i * 16 + frow;                                                       \
+                wf[i] = *reinterpret_cast<const f16x8*>(sWh + row * 128 + choff);                                \
+                wl[i] = *reinterpret_cast<const f16x8*>(sWl + row * 128 + choff);                                \
+            }                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+                const int row = j * 16 + frow;                                                                   \
+                xh[j] = *reinterpret_cast<const f16x8*>(sXh + row * 128 + choff);                                \
+                xl[j] = *reinterpret_cast<const f16x8*>(sXl + row * 128 + choff);                                \
+            }                                                                                                    \
+            /* smallest terms first: the two cross terms, then the main product */                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+                    acc[i][j] = JG_MFMA_16x16x32(wl[i], xh[j], acc[i][j]);                                       \
+                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xl[j], acc[i][j]);                                       \
+                    acc[i][j] = JG_MFMA_16x16x32(wf[i], xh[j], acc[i][j]);                                       \
+                }                                                                                                \
+        }                                                                                                        \
+    }
+    X3_LOAD(0, 0)          // nk >= DEPTH (K % 256 == 0)
+    X3_LOAD(1, 1)
+    X3_LOAD(2, 2)
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+        X3_TILE(0, kt0)
+        X3_TILE(1, kt0 + 1)
+        X3_TILE(2, kt0 + 2)
+        X3_TILE(3, kt0 + 3)
+    }
+#undef X3_TILE
+#undef X3_LOAD
     // lane holds D[n = 4 fq + r][m = frow] of each 16 x 16 tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int n = n0 + wave * 32 + i * 16 + fq * 4;
         const f32x4 bi = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int m = m0 + j * 16 + frow;
             if (m >= a.M) continue;
             f32x4 v = acc[i][j] + bi;
@@ -491,10 +495,10 @@ hipError_t launch_zero_tail32(float* x, const int* valid, int halvings, int B, i
 
 hipError_t launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
-    if (!a.A || !a.Wh || !a.Wl || !a.out || a.K <= 0 || a.K % 64 || a.N <= 0 || a.N % 128 || (a.lda & 3) || (a.ldw & 7) || (a.ldc & 3) || (a.res && (a.ldr & 3)) ||
+    if (!a.A || !a.Wh || !a.Wl || !a.out || a.K <= 0 || a.K % 256 || a.N <= 0 || a.N % 128 || (a.lda & 3) || (a.ldw & 7) || (a.ldc & 3) || (a.res && (a.ldr & 3)) ||
         ((uintptr_t)a.A & 15))
         return hipErrorInvalidValue;
-    const long tiles = (long)((a.M + 63) / 64) * (a.N / 128);
+    const long tiles = (long)((a.M + 31) / 32) * (a.N / 128);
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -24,7 +24,7 @@ def short(name):
     for key in ("conv1_direct_kernel", "conv1_zero_scan_kernel", "conv1_skip_mask_kernel", "conv1_edge_fix_kernel", "attn_mfma_s32_kernel",
                 "rc_col_mean_kernel", "rc_gemv_kernel", "attn_mfma_kernel", "attn_kernel", "layernorm_kernel", "window_gather_tiled_kernel", "window_gather_kernel", "group_mean_kernel",
                 "maxpool_kernel", "l2norm_kernel", "cast_kernel", "pe_project_kernel", "conv_rowmap_scan_kernel", "conv_rowmap_fill_kernel",
-                "unpack_masked_kernel", "segment_mean_kernel", "audio_conv0_kernel", "gemm_kernel"):
+                "unpack_masked_kernel", "segment_mean_kernel", "audio_conv0_kernel", "gemm_x3_kernel", "gemm32_kernel", "attention32_kernel", "gemm_kernel"):
         if key in name:
             if key == "attn_mfma_s32_kernel":
                 return key + ("<gather>" if "ILb1E" in name else "")
