@@ -93,6 +93,8 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
  *   "num_cu"          workgroups a persistent kernel launches (default: the device's CU count; experiment)
  *   "gesture_lanes"   0 (default): two lanes split 3:5; 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
+ *   "xlmr_lanes"      1 (default) .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams.  More than one part is an
+ *                     EXPERIMENT since round 6: rare run-to-run differences under a poisoned workspace, root cause open (api.hip, jg_handle::xl_lanes)
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a
  *                     kernel that reads a row nobody wrote (the row / band skips leave rows unwritten on purpose) shows up as NaN
  *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug)

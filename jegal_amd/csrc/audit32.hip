@@ -419,6 +419,10 @@ __global__ __launch_bounds__(256) void zero_tail32_kernel(float* __restrict__ x,
     for (int i = threadIdx.x; i < row_vec; i += 256) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+__global__ void poison_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+
 inline int grid_for(long total) { return (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4); }
 
 }  // namespace
@@ -500,5 +504,11 @@ hipError_t launch_gemm_x3(const GemmX3Args& a, hipStream_t s) {
         return hipErrorInvalidValue;
     const long tiles = (long)((a.M + 31) / 32) * (a.N / 128);
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_poison(void* p, size_t bytes, hipStream_t s) {
+    if (!p || bytes < 16) return hipSuccess;
+    hipLaunchKernelGGL(poison_kernel, dim3(4096), dim3(256), 0, s, reinterpret_cast<uint4*>(p), bytes / 16);
     return hipGetLastError();
 }

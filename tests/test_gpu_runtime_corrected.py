@@ -185,3 +185,20 @@ def test_rc_long_clip_whole_path(rc):
     r, mx = rel(emb[0], g), float(np.abs(emb[0] - g).max())
     print(f"\nRC T = {T}: embedding rel-L2 {r:.3e} max-abs {mx:.3e}", end="")
     assert r < TOL and mx < TOL
+
+
+def test_two_lane_gesture_path_is_reproducible_under_a_poisoned_workspace(rc):
+    """Companion of test_xlmr_is_reproducible_under_a_poisoned_workspace (round 6): 32 clips run as two lanes on two streams; with the
+    workspace filled with NaN bytes before every chunk, a read of anything the step has not written itself cannot hide behind the
+    previous run's values.  40 runs, every GEMM tile choice: bit-identical."""
+    frames = torch.from_numpy(synth.synth_frames(5, 32, 30)).cuda()
+    base = rc.extract_gesture(frames).clone()
+    assert torch.isfinite(base).all()
+    rc.set_option("ws_poison", 1)
+    try:
+        for it in range(40):
+            rc.set_option("gemm_tile", it & 3)
+            assert torch.equal(rc.extract_gesture(frames), base), it
+    finally:
+        rc.set_option("ws_poison", 0)
+        rc.set_option("gemm_tile", 0)

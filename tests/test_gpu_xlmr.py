@@ -311,3 +311,29 @@ def test_dataset_driver_runs_xlmr_on_the_engine_batch_invariant(tmp_path, monkey
         worst = max(worst, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
     print(f"\nphrases -> XLM-R on the engine -> content embeddings, 8 ragged sentences in one batch vs the oracle on each alone: rel-L2 {worst:.2e}")
     assert worst < TOL
+
+
+def test_xlmr_is_reproducible_under_a_poisoned_workspace():
+    """Round 6.  In steady state an uninitialised or stale read of the workspace returns the PREVIOUS identical run's value and stays
+    invisible; with option ws_poison the arena is filled with NaN bytes before every call, so run-to-run bit-identity becomes a
+    real test.  (With two parts in flight -- option xlmr_lanes = 2, the round-5 default -- 10-40 % of such runs differed on some
+    sequences: tools/xl_poison_probe.py; the default is one part since.)"""
+    from jegal_amd._lib import Engine
+    from jegal_amd.xlmr import XLMRoberta
+    eng = Engine(0)
+    try:
+        m = XLMRoberta(engine=eng).load_state_dict(synth.xlmr_state_dict(layers=2))
+        for B, L in ((64, 32), (24, 40)):
+            ids, mask = synth.xlmr_inputs(3, B, L)
+            ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+            eng.set_option("ws_poison", 0)
+            base = m(ids_d, attention_mask=mask_d).last_hidden_state.clone()
+            assert torch.isfinite(base).all()
+            eng.set_option("ws_poison", 1)
+            for it in range(40):
+                eng.set_option("gemm_tile", it & 3)
+                out = m(ids_d, attention_mask=mask_d).last_hidden_state
+                assert torch.equal(out, base), (B, L, it)
+    finally:
+        eng.set_option("gemm_tile", 0)
+        eng.close()
