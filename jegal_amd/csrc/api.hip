@@ -1678,7 +1678,11 @@ int jegal_text_impl(jg_handle* h, const float* states, const float* mask, int B,
     RET(wsalloc(h, (size_t)M * 768, &x32));
     RET(wsalloc(h, (size_t)M * 768, &n16));
     HIPCHK(h, hipMemcpyAsync(x32, states, (size_t)M * 768 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    RET(annotated_encoder(h, h->text_layers, 3, h->text_norm, x32, n16, mask, B, L, 768, 3072));
+    const bool x3 = h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->op_text.wl;
+    float* n32 = nullptr;
+    if (x3) RET(wsalloc(h, (size_t)M * 768, &n32));
+    RET(annotated_encoder(h, h->text_layers, 3, h->text_norm, x32, n16, mask, B, L, 768, 3072, 0, n32));
+    if (x3) return gemm_x3(h, JG_ST_GEMM, n32, 768, M, h->op_text, out);      // proj_op_text from the final norm's fp32 rows (round 6)
     Epi o; o.out32 = out;
     return gemm(h, JG_ST_GEMM, n16, 768, M, h->op_text, o);
 }
@@ -1882,6 +1886,18 @@ int fuse_content_impl(jg_handle* h, const float* fused, int rows, float* out) {
     if (!h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "JEGAL weights not finalized");
     if (rows <= 0) JG_FAIL(h, JG_ERR_ARG, "rows must be positive");
     if (audit_mask(h) & AUD_CONTENT) return fuse_content_impl32(h, fused, rows, out);
+    // round 6: like the gesture branch's ends, the content path's last four GEMMs keep fp32 activations and run on the split-operand
+    // kernel (fp32-grade products on the fp16 matrix cores; a few hundred rows: the cost is a launch either way)
+    if (h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->fu0.wl && h->fu2.wl && h->al_c0.wl && h->al_c2.wl) {
+        float *a32, *b32;
+        RET(wsalloc(h, (size_t)rows * 512, &a32));
+        RET(wsalloc(h, (size_t)rows * 512, &b32));
+        Epi32 r; r.act = 1;
+        RET(gemm_x3(h, JG_ST_GEMM, fused, 512, rows, h->fu0, a32, r));
+        RET(gemm_x3(h, JG_ST_GEMM, a32, 512, rows, h->fu2, b32));
+        RET(gemm_x3(h, JG_ST_GEMM, b32, 512, rows, h->al_c0, a32, r));
+        return gemm_x3(h, JG_ST_GEMM, a32, 512, rows, h->al_c2, out);
+    }
     f16 *x16, *a16, *b16;
     RET(wsalloc(h, (size_t)rows * 512, &x16));
     RET(wsalloc(h, (size_t)rows * 512, &a16));

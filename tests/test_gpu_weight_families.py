@@ -15,9 +15,9 @@ branch alone amplifies x 24: a 1e-4 input perturbation moves its fp64 output by 
 operand; the reference's own CUDA autocast path is the same arithmetic) can hold 1e-3 there.
 
 Round 6 (VERDICT r5 item 2 / ADVICE r5): the widened bound (1e-3 x factor ratio / 3, which let a 33 % error pass) is gone.  Every family also runs
-in the fp32 AUDIT mode (JG_PREC_FP32: exact-fp32 MFMAs, fp32 activations), which must reproduce the fp32 oracle on EVERY family, `sharp`
-included (the bound is 2e-5 for networks in the regime and scales with the measured fp64 conditioning beyond it -- fp32 summation order
-is amplified like any other perturbation; the measured values are printed).  Rule for the fp16 modes: a family whose conditioning is
+in the fp32 AUDIT mode (JG_PREC_FP32: exact-fp32 MFMAs, fp32 activations), which must reproduce the fp32 oracle to 2e-5 on EVERY family,
+`sharp` included (gesture / content path: measured 1.1e-6 .. 5.9e-6; for XLM-RoBERTa, whose `sharp` draw amplifies perturbations 7 400 x,
+the bound scales with the measured conditioning beyond the regime -- fp32 summation order is a perturbation like any other).  Rule for the fp16 modes: a family whose conditioning is
 within 3 x the Gaussian draw's must meet the plain 1e-3 in the mode the drivers select.  Beyond that no 16-bit operand format can
 (reported), and the test asserts what a user WITHOUT an oracle would see: the distance between the default mode and the audit mode --
 what `python -m jegal_amd.drivers inference_embs ... --audit` prints -- equals the true error to the audit mode's own accuracy, so the
@@ -127,7 +127,7 @@ def test_gesture_and_content_across_weight_families(family):
     amp, amp_ref = amplification(gt, jt, conv0), gauss_amplification(frames[0])
     ratio = amp / amp_ref
     in_regime = ratio <= 3.0
-    aud_bound = AUD_TOL * max(1.0, ratio / 3.0)
+    aud_bound = AUD_TOL          # the gesture / content path: the plain 2e-5 on every family, `sharp` included (measured 1.1e-6 .. 5.9e-6)
     print(f"\n[{fam_id(family)}] conditioning (fp64, d embedding / d conv features): {amp:.3f} = {ratio:.1f} x the Gaussian draw's -> "
           f"{'in the regime of the 1e-3 contract' if in_regime else 'OUTSIDE the regime of any 16-bit operand format: fp16 modes reported, audit mode asserted'}", end="")
     record(f"{fam_id(family)}/conditioning", amplification=amp, ratio_to_gauss=ratio, in_regime=in_regime, audit_bound=aud_bound)
