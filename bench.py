@@ -59,7 +59,7 @@ def load_traffic():
     """Per-launch HBM traffic of the dominant kernel from the committed counter passes (profiles/r2_pmc_summary.json,
     written by tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
     command).  None when the summary is absent."""
-    for name in ("r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json"):          # the newest committed counter passes
+    for name in ("r6_pmc_summary.json", "r5_pmc_summary.json", "r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json"):          # the newest committed counter passes
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             break
@@ -76,7 +76,7 @@ def load_sq_counters():
     """SQ / GRBM counters of the dominant kernel from the committed passes (profiles/r4_sq_summary.json, written by tools/sq_summary.py
     from `rocprofv3 --pmc` runs of this command: tools/profile_sq.sh): MFMA-pipe busy fraction of the kernel's cycles, the clock
     GRBM_GUI_ACTIVE implies for the dispatch, LDS bank-conflict share.  None when no summary is committed."""
-    for name in ("r5_sq_summary.json", "r4_sq_summary.json", "r4a_sq_summary.json"):
+    for name in ("r6_sq_summary.json", "r5_sq_summary.json", "r4_sq_summary.json", "r4a_sq_summary.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             k = json.load(open(p)).get("conv1_direct_kernel")

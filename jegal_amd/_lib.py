@@ -240,7 +240,8 @@ class Engine:
     def gestsync_clip(self, frames, lengths=None):
         """frames (B,T,270,480,3) uint8 or float32 cuda tensor -> (B,T,1024) fp32.  lengths (B ints, optional): frames of each clip
         that are its own in a batch padded to T with copies of the clips' last frames (jg_gestsync_clip_ragged): rows t < lengths[b]
-        of clip b are then what the clip gives alone, whatever T is."""
+        of clip b are then what the clip gives alone, whatever T is (bit for bit for clips of >= 49 frames; a shorter clip alone takes
+        the unfused plan and agrees within the contract, include/jegal_hip.h)."""
         self._bind_stream()
         frames, code, B, T = self._frames_arg(frames)
         out = torch.empty((B, T, 1024), dtype=torch.float32, device=self.device)

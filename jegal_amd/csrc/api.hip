@@ -206,10 +206,12 @@ struct jg_handle {
     Lin a0, a3, a6, a9, a12, a15;
     float* feats = nullptr;
     size_t feats_cap = 0;
-    std::vector<int32_t> audio_valid[4];   // host copies of the last four jg_jegal_audio_ragged calls' valid lengths (sources of stream-ordered uploads)
-    unsigned audio_valid_next = 0;
-    std::vector<int32_t> clip_valid[8];    // ... and of the last eight jg_gestsync_clip_ragged parts' valid row counts
-    unsigned clip_valid_next = 0;
+    // Small host -> device uploads that a call enqueues on its stream (per-clip lengths): a ring of PINNED staging slots, each guarded by
+    // an event recorded behind its copy, so a slot is re-used only once that copy has run (pageable vectors kept "alive for
+    // seven more parts" relied on the runtime staging pageable copies synchronously and on no caller enqueueing more than eight parts ahead)
+    struct StageSlot { int32_t* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    StageSlot stage_ring[16];
+    unsigned stage_next = 0;
     // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
@@ -320,6 +322,25 @@ int wsalloc(jg_handle* h, size_t n, T** out) {
     void* p = h->ws.alloc(n * sizeof(T), &e);
     if (!p) JG_FAIL(h, JG_ERR_HIP, "workspace allocation of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
     *out = reinterpret_cast<T*>(p);
+    return JG_OK;
+}
+
+// n int32 values from the host into `dst` (device) on the handle's stream, through the pinned staging ring (jg_handle::stage_ring)
+int upload_i32_async(jg_handle* h, const int32_t* src, size_t n, int32_t* dst) {
+    jg_handle::StageSlot& sl = h->stage_ring[h->stage_next++ & 15];
+    if (sl.pending) { HIPCHK(h, hipEventSynchronize(sl.ev)); sl.pending = false; }
+    if (!sl.ev) HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.cap < n) {
+        if (sl.host) HIPCHK(h, hipHostFree(sl.host));
+        sl.host = nullptr; sl.cap = 0;
+        const size_t cap = n < 256 ? 256 : n;
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&sl.host), cap * sizeof(int32_t), hipHostMallocDefault));
+        sl.cap = cap;
+    }
+    std::memcpy(sl.host, src, n * sizeof(int32_t));
+    HIPCHK(h, hipMemcpyAsync(dst, sl.host, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(sl.ev, h->stream));
+    sl.pending = true;
     return JG_OK;
 }
 
@@ -1188,10 +1209,8 @@ int jegal_audio_impl32(jg_handle* h, const float* mel, int B, int Tm, const int3
             ragged |= valid_host[b] != Tm;
         }
         if (ragged) {
-            std::vector<int32_t>& hv = h->audio_valid[h->audio_valid_next++ & 3];
-            hv.assign(valid_host, valid_host + B);
             RET(wsalloc(h, (size_t)B, &valid));
-            HIPCHK(h, hipMemcpyAsync(valid, hv.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+            RET(upload_i32_async(h, valid_host, (size_t)B, valid));
         }
     }
     float *m0, *c0, *c3, *c6, *c9, *c12, *c15;
@@ -1317,11 +1336,10 @@ int gestsync_clip_impl(jg_handle* h, const void* frames, int dtype, int B, int T
         const bool tiled = gs_fused_plan(h, M, T * S);
         int* rc_valid = nullptr;
         if (valid_host && tiled && h->precision == JG_PREC_FP16_RC) {
-            std::vector<int32_t>& hv = h->clip_valid[h->clip_valid_next++ & 7];      // stays alive for seven more parts: the copy is stream-ordered
-            hv.resize(nb);
+            std::vector<int32_t> hv(nb);
             for (int b = 0; b < nb; ++b) hv[b] = valid_host[b0 + b] * S;              // rows = frames x 21 tokens
             RET(wsalloc(h, (size_t)nb, &rc_valid));
-            HIPCHK(h, hipMemcpyAsync(rc_valid, hv.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, h->stream));
+            RET(upload_i32_async(h, hv.data(), (size_t)nb, rc_valid));
         }
         // layer-0 qkv from the distinct conv positions: worth it when the windows overlap (T > 1) and the MFMA attention runs
         const bool lin0 = tiled && h->qkv0_linear && h->opts.attn_mfma && T > 1;
@@ -1635,10 +1653,8 @@ int jegal_audio_impl(jg_handle* h, const float* mel, int B, int Tm, const int32_
             ragged |= valid_host[b] != Tm;
         }
         if (ragged) {
-            std::vector<int32_t>& hv = h->audio_valid[h->audio_valid_next++ & 3];      // stays alive for three more calls: the copy is stream-ordered
-            hv.assign(valid_host, valid_host + B);
             RET(wsalloc(h, (size_t)B, &valid));
-            HIPCHK(h, hipMemcpyAsync(valid, hv.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+            RET(upload_i32_async(h, valid_host, (size_t)B, valid));
         }
     }
     f16 *c0, *c3, *c6, *c9, *c12, *c15;
@@ -2001,6 +2017,7 @@ int jg_destroy(jg_handle* h) {
         for (int e = 0; e < jg_handle::MAX_LANES + 1; ++e) if (h->lane_ev[e]) (void)hipEventDestroy(h->lane_ev[e]);
         engine_opts_release(h->opts);
         if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+        for (auto& sl : h->stage_ring) { if (sl.ev) (void)hipEventDestroy(sl.ev); if (sl.host) (void)hipHostFree(sl.host); }
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     }
     delete h;

@@ -149,7 +149,8 @@ def cmd_extract_gestsync_feats(argv):
             fr = np.load(f)
             batch[i, :t] = fr
             batch[i, t:] = fr[t - 1]
-        # (the lengths keep each clip's run-time precision correction on its OWN frames: rows < t are those of the clip alone)
+        # (the lengths keep each clip's run-time precision correction on its OWN frames: rows < t are those of the clip alone -- bit for bit
+        # from 49 frames on, within the contract below: include/jegal_hip.h, jg_gestsync_clip_ragged)
         feats = gs.extract_clip_feats(torch.from_numpy(batch).to(eng.device), lengths=[t for t, _, _ in group]).cpu().numpy()
         return [feats[i, :t] for i, (t, _, _) in enumerate(group)]
 

@@ -598,3 +598,29 @@ def test_bench_launcher_starts_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def test_c_abi_rccl_exchange_world_of_one():
+    """jg_comm_* / jg_allgather / jg_allreduce_sum_i64 (round 6; SURVEY 8b lists jg_allgather): the exchange primitive of the retrieval
+    metric for a consumer of the C ABI without PyTorch, on RCCL bound with dlopen.  One GPU here: a communicator of ONE rank (the collective
+    code path, ids, streams and the gallery assembly are the same as with eight); with two visible devices a second handle joins."""
+    from jegal_amd._lib import Engine
+    eng = Engine(0)
+    try:
+        uid = Engine.comm_unique_id()
+        assert isinstance(uid, bytes) and len(uid) == 128
+        eng.comm_init(uid, 0, 1)
+        ge, ce = synth.planted_retrieval(1237, 512)
+        e1, e2 = eng.l2norm(torch.from_numpy(ce)), eng.l2norm(torch.from_numpy(ge))
+        gallery = eng.allgather(e2)
+        assert gallery.shape == e2.shape and torch.equal(gallery, e2)
+        rank, ties = eng.sim_rank(e1, gallery)
+        ref_rank, ref_ties = eng.sim_rank(e1, e2)
+        assert torch.equal(rank, ref_rank) and torch.equal(ties, ref_ties)
+        counts = eng.allreduce_sum_i64([int((rank < k).sum()) for k in (1, 5, 10, 25, 50)])
+        assert counts.cpu().tolist() == [int((ref_rank < k).sum()) for k in (1, 5, 10, 25, 50)]
+        eng.comm_destroy()
+        with pytest.raises(Exception):
+            eng.allgather(e2)                               # no communicator any more
+    finally:
+        eng.close()

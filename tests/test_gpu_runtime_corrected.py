@@ -172,6 +172,33 @@ def test_rc_padded_batch_with_lengths_equals_the_clips_alone(rc):
         rc.gestsync_clip(torch.from_numpy(clips[0][None]).cuda(), lengths=[61])          # beyond T
 
 
+def test_rc_short_clip_in_a_padded_batch_is_within_tolerance_of_itself_alone(rc):
+    """the bit-identity of jg_gestsync_clip_ragged's kept rows with the clip run alone holds for clips of >= 49 frames (alone
+    they take the same fused plan).  A 30-frame clip alone has 630 token rows < 1 024 and runs the unfused hi+lo plan; padded to 64 frames
+    next to a longer clip it runs the fused run-time corrected plan: equal within the contract, not bit for bit -- and still independent
+    of the padding length and of its neighbour."""
+    gsd = O.tensors(synth.gestsync_state_dict(include_unused=False))
+    lens = [30, 64]
+    clips = [synth.synth_frames(170 + i, 1, t)[0] for i, t in enumerate(lens)]
+
+    def padded(Tpad, order=(0, 1)):
+        batch = np.empty((2, Tpad, 270, 480, 3), np.uint8)
+        for slot, i in enumerate(order):
+            batch[slot, :lens[i]] = clips[i]
+            batch[slot, lens[i]:] = clips[i][-1]
+        out = rc.gestsync_clip(torch.from_numpy(batch).cuda(), lengths=[lens[i] for i in order])
+        return {i: out[slot, :lens[i]].clone() for slot, i in enumerate(order)}
+    a, b, c = padded(64), padded(80), padded(64, order=(1, 0))
+    alone = rc.gestsync_clip(torch.from_numpy(clips[0][None]).cuda())[0]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0])          # independent of padding length and batch position
+    d = rel(a[0], alone)
+    with torch.no_grad():
+        ref = O.gestsync_clip_feats(gsd, torch.from_numpy(clips[0].astype(np.float32) / np.float32(255.0)))
+    print(f"\n30-frame clip: padded batch (fused plan) vs alone (unfused hi+lo plan) rel-L2 {d:.2e}; vs the oracle {rel(a[0], ref):.2e} / {rel(alone, ref):.2e}", end="")
+    assert d < 3e-4 and rel(a[0], ref) < TOL and rel(alone, ref) < TOL
+    assert torch.equal(a[1], rc.gestsync_clip(torch.from_numpy(clips[1][None]).cuda())[0])      # the 64-frame clip: bit-identical to itself alone
+
+
 def test_rc_long_clip_whole_path(rc):
     """One 260-frame clip (longer than any AVS clip: 220) through the whole gesture path in the default mode: 5 460 token rows per
     clip (the every-eighth-run sample: 43 runs), the JEGAL branch on the online-softmax attention (S = 260 > 160)."""
