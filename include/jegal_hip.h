@@ -151,7 +151,7 @@ int jg_gestsync_clip(jg_handle* h, const void* frames, int frames_dtype, int B, 
  * valid_frames_host (host [B], 1..T): frames of clip b that are its own.  JG_PREC_FP16_RC takes each clip's run-time correction from
  * its own rows only, so rows t < valid_frames[b] of clip b do not depend on T or on the other clips, and for clips of >= 49 frames
  * they are bit-identical to the clip run alone.  (A clip of fewer than 49 frames ALONE has fewer than 1 024 token rows and takes the
- * unfused hi+lo plan, in a padded batch the fused one: the two agree within the contract -- tests: <= 3e-4 -- not bit for bit.)  The
+ * unfused hi+lo plan, in a padded batch the fused one: each within the 1e-3 contract of the reference, 5e-4 apart in the test -- not bit for bit.)  The
  * other modes ignore the lengths.  Rows t >= valid_frames[b] of the output are padding for the caller to strip. */
 int jg_gestsync_clip_ragged(jg_handle* h, const void* frames, int frames_dtype, int B, int T, const int32_t* valid_frames_host, float* out_feats);
 /* Kernel-level check point: conv1+BN+ReLU+maxpool (gestsync.py:36-46) only.  frames (B,T,270,480,3) u8,

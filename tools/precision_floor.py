@@ -96,6 +96,8 @@ def main():
         if args.quick:
             table[fam] = rows
             continue
+        # what remains in the round-6 default, by stage
+        run("rc default", L.PREC_FP16_RC, aw=True, masks=(1, 2, 4, 3, 5, 6, 7))
         extra = extra + [("jegal_fp32_ends", 0), ("conv_round_diffuse", 0)]          # the decomposition below is of the round-5 arithmetic
         run("rc", L.PREC_FP16_RC, aw=True, masks=(0, 1, 2, 4, 3, 5, 6, 7), opts=extra)
         # inside the JEGAL branch, on exact GestSync features (stages 3): 1 input projection, 2 attention sub-layers, 4 feed-forward
