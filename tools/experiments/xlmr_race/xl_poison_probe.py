@@ -36,6 +36,9 @@ for it in range(150):
         seqs |= set(int(b) for b, _ in bad)
 print(f"opts {os.environ.get('OPTS')} sel {os.environ.get('SEL')} lanes {lanes} fold {fold} calibrated {cal} B {B} L {L}: runs with differences: {n} of 150; sequences {sorted(seqs)}")
 import ctypes
+eng.lib.jg_debug_counter.restype = ctypes.c_int64
+eng.lib.jg_debug_counter.argtypes = [ctypes.c_void_p, ctypes.c_int]
+print("shadow launches, differing 16-byte words over all runs [attention, qkv, stats@qkv, ff1, stats@ff1]:", [eng.lib.jg_debug_counter(eng.h, i) for i in range(5)])
 buf = (ctypes.c_int64 * 96)()
 eng.lib.jg_debug_arenas.restype = ctypes.c_int
 nchunks = eng.lib.jg_debug_arenas(eng.h, buf, 32)
