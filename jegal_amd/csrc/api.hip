@@ -244,7 +244,7 @@ struct jg_handle {
     // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams.  Default 1 since round 6: with two
     // parts in flight the implicit-LayerNorm pass returned, in 10-40 % of the runs under a POISONED workspace (option ws_poison: stale
     // bytes are NaN instead of the previous, identical run's values), ~1e-2 errors on some sequences of one part -- never with one part, never
-    // with xlmr_fold = 0 or attn_mfma = 0 (tools/xl_poison_probe.py; the gesture path's two lanes: 0 of 150, tools/gesture_race_probe.py).
+    // with xlmr_fold = 0 or attn_mfma = 0 (tools/experiments/xlmr_race/xl_poison_probe.py; the gesture path's two lanes: 0 of 150, tools/experiments/xlmr_race/gesture_race_probe.py).
     // Root cause not found; until it is, more than one part is an experiment (-8 % XLM-R throughput at B = 256, L = 64).
     int xl_lanes = 1;
 };

@@ -64,5 +64,5 @@ hipError_t launch_gemm_x3(const GemmX3Args& a, hipStream_t s);
 
 // Test aid (option ws_poison): fill with 0xff bytes (fp16 / fp32 NaN) by a kernel of our own on the stream -- NOT hipMemsetAsync: two 1-GiB
 // hipMemsetAsync fills running concurrently on two streams were observed to overlap the kernels enqueued BEHIND them on their own stream
-// (tools/xl_poison_probe.py, round 6)
+// (tools/experiments/xlmr_race/xl_poison_probe.py, round 6)
 hipError_t launch_poison(void* p, size_t bytes, hipStream_t s);

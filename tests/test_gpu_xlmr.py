@@ -317,7 +317,7 @@ def test_xlmr_is_reproducible_under_a_poisoned_workspace():
     """Round 6.  In steady state an uninitialised or stale read of the workspace returns the PREVIOUS identical run's value and stays
     invisible; with option ws_poison the arena is filled with NaN bytes before every call, so run-to-run bit-identity becomes a
     real test.  (With two parts in flight -- option xlmr_lanes = 2, the round-5 default -- 10-40 % of such runs differed on some
-    sequences: tools/xl_poison_probe.py; the default is one part since.)"""
+    sequences: tools/experiments/xlmr_race/xl_poison_probe.py; the default is one part since.)"""
     from jegal_amd._lib import Engine
     from jegal_amd.xlmr import XLMRoberta
     eng = Engine(0)
