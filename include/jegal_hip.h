@@ -98,6 +98,15 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a
  *                     kernel that reads a row nobody wrote (the row / band skips leave rows unwritten on purpose) shows up as NaN
  *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug)
+ *   "jegal_fp32_ends" 1 (default): the two ends of the JEGAL gesture branch (proj_ip_rgb; final norm + proj_op_rgb + proj_op_align_gesture) and
+ *                     of the content path (proj_op_text, fusion / align MLPs) keep fp32 activations and run on the split-operand GEMM
+ *                     (three fp16 MFMAs per tile: fp32-grade products); 0: the round-5 arithmetic (fp16 activations, hi+lo weights).  DESIGN.md section 3
+ *   "conv_round_diffuse" 1 (default; before jg_finalize_weights): conv weights are rounded to fp16 with error diffusion across the taps of each
+ *                     (output channel, input slot) pair instead of round-to-nearest per weight (the pixel-independent part of the rounding error vanishes)
+ *   "rc_layers"       measurement only: mask of the GestSync Linear types that get JG_PREC_FP16_RC's run-time correction (1 qkv, 2 out_proj,
+ *                     4 linear1 / ff_vid.0, 8 linear2; default 15); the others run single fp16 WITHOUT a correction
+ *   "audit_jegal_parts" measurement only (needs audit_weights): parts of the fp16 JEGAL gesture branch on the fp32 kernels (1 input projection,
+ *                     2 attention sub-layers, 4 feed-forward sub-layers, 8 final norm + output projections)
  *   "audit_weights"   1 (before jg_finalize_weights): the fp32 matrices are kept next to the packed fp16 ones (always in JG_PREC_FP32)
  *   "audit_stages"    mask of the stages that run on the fp32 audit kernels (needs audit_weights): 1 GestSync conv stack, 2 GestSync
  *                     transformer + ff_vid, 4 JEGAL gesture branch, 8 JEGAL content path (audio / text / fusion), 16 XLM-RoBERTa.  The

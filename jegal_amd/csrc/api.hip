@@ -159,7 +159,6 @@ struct jg_handle {
     f16* gs_qpe = nullptr;         // [21][1536]: layer-0 W_qkv pe[j] + b (Qkv0); recomputed when weights or bias corrections change
     bool gs_qpe_valid = false;
     bool qkv0_linear = true;       // layer-0 qkv projection over the distinct conv positions + gather in the attention kernel
-    int ws_poison_sel = 0;         // debug (option "ws_poison_sel"): jg_xlmr_encode poisons 0 every part's arena, 1 only the first part's, 2 only the others'
     bool ws_poison = false;        // option "ws_poison": fill the workspace with 0xff before every clip chunk (tests)
     bool conv2_row_skip = true;    // conv2 leaves out the leading output rows that the zero-band scan proves to be copies of one row
     const int* last_rowskip = nullptr;   // device word: min over the last conv stack's positions of conv2's row skip (jg_debug_conv2_rowskip)
@@ -2083,7 +2082,6 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv1_zero_skip")) { o.conv1_zero_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
-    if (!std::strcmp(name, "ws_poison_sel")) { h->ws_poison_sel = value; return JG_OK; }
     if (!std::strcmp(name, "rc_layers")) { h->rc_layers = value & 15; return JG_OK; }
     if (!std::strcmp(name, "jegal_fp32_ends")) { h->jegal_fp32_ends = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv_round_diffuse")) {
@@ -2423,7 +2421,7 @@ int jg_xlmr_encode(jg_handle* h, const int32_t* input_ids, const int32_t* attent
     // kernels start on the CUs the other's last round leaves idle.
     auto run_part = [&](int b0, int nb) -> int {
         h->ws.reset();
-        if (h->ws_poison && (h->ws_poison_sel == 0 || (h->ws_poison_sel == 1) == (b0 == 0)))      // test aid: whatever a kernel reads without having written it is NaN
+        if (h->ws_poison)                       // test aid: whatever a kernel reads without having written it is NaN
             for (auto& c : h->ws.chunks) HIPCHK(h, launch_poison(c.p, c.cap, h->stream));
         return xlmr_encode_impl(h, input_ids + (size_t)b0 * L, attention_mask ? attention_mask + (size_t)b0 * L : nullptr, nb, L,
                                 out + (size_t)b0 * L * 768);
@@ -2592,19 +2590,6 @@ int jg_profile_reset(jg_handle* h) {
     RET(prof_collect(h));
     for (int i = 0; i < JG_ST_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
     return JG_OK;
-}
-
-// debug: (pointer, capacity) of every chunk of the caller-stream arena (tag 0) and of the lane arenas (tag 1 + lane), up to max_chunks triples
-int jg_debug_arenas(jg_handle* h, int64_t* out, int max_chunks) {
-    if (!h || !out) return 0;
-    int n = 0;
-    auto dump = [&](const Arena& a, int tag) {
-        for (auto& c : a.chunks)
-            if (n < max_chunks) { out[3 * n] = tag; out[3 * n + 1] = (int64_t)(uintptr_t)c.p; out[3 * n + 2] = (int64_t)c.cap; ++n; }
-    };
-    dump(h->ws, 0);
-    for (int l = 0; l < jg_handle::MAX_LANES; ++l) dump(h->lane_ws[l], 1 + l);
-    return n;
 }
 
 int64_t jg_workspace_bytes(jg_handle* h) {
