@@ -386,6 +386,31 @@ def main():
     conv_rows, conv_rows_full = eng.debug_conv_rows()       # output pixels conv2 .. conv5 computed / would compute without the skip
 
     extras = {}
+    if not args.no_extras and rank == 0 and args.precision != 6:
+        # Parity of THIS run's embeddings, measured live (round 6): two of the timed clips once more on a JG_PREC_FP32 audit engine (exact-fp32
+        # MFMAs, fp32 activations: the reference's CPU arithmetic on the device, itself 1e-6 from the CPU oracle -- tests/test_gpu_audit_fp32.py,
+        # and from the cpu_baseline port below on the same clips) and the rel-L2 / max-abs of the timed mode against it
+        try:
+            from jegal_amd._lib import PREC_FP32
+            e32 = Engine(local_dev, precision=PREC_FP32)
+            try:
+                GestSync(engine=e32).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+                JEGAL(engine=e32).load_state_dict(synth.jegal_state_dict())
+                eng.extract_gesture(frames, out)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ref32 = e32.extract_gesture(frames[:2]).double()
+                torch.cuda.synchronize()
+                t32 = time.perf_counter() - t0
+                got = out[:2].double()
+                extras["audit"] = {"engine": "JG_PREC_FP32 (audit mode)", "clips": 2,
+                                   "gesture_rel_l2": float((got - ref32).norm() / ref32.norm()),
+                                   "gesture_max_abs": float((got - ref32).abs().max()), "tolerance": 1e-3,
+                                   "audit_clips_per_s": 2.0 / t32}
+            finally:
+                e32.close()
+        except Exception as exc:  # noqa: BLE001
+            extras["audit"] = {"error": repr(exc)[:200]}
     if not args.no_extras:
         # the same step on frames with no zero rows (timing only): every conv1 tile is computed
         dense = torch.randint(0, 256, frames.shape, dtype=torch.uint8, device=dev)
@@ -651,6 +676,8 @@ def main():
             res["spotting_config5"] = extras["spotting"]
             if "config3" in extras:
                 res["config3"] = extras["config3"]
+            if "audit" in extras:
+                res["config"]["parity_of_this_run"] = extras["audit"]
             # the driver keeps `config` whole (other top-level keys are reduced to their names): the numbers a reader of the headline needs
             res["config"]["value_is"] = "masked synthetic clips (rows 0..109 zero, BASELINE configs[1]), precision mode JG_PREC_FP16_RC, two lanes"
             res["config"]["same_loop_other_inputs_clips_per_s"] = {"dense_frames_no_zero_row": round(res["value_dense"]["value"], 1),
