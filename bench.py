@@ -266,7 +266,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=CLIPS)
     ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--precision", type=int, default=5, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (opt-in: needs a calibration), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16 (the library default: calibration-free)")
+    ap.add_argument("--precision", type=int, default=5, help="0 fp16, 1 hi+lo Linear weights, 2 hi+lo everywhere, 3 bias-corrected fp16 (opt-in: needs a calibration), 4 bf16 (reported mode: outside the 1e-3 contract), 5 run-time corrected fp16 (the library default: calibration-free), 6 fp32 audit mode (~50 clips/s: use --steps 2 --warmup 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (dense conv1, sustained loop, PCIe stream, retrieval)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
@@ -606,7 +606,7 @@ def main():
             "metric": "clips/sec (T=150 frames, 270x480) embedding extraction", "value": value, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == 4 else "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == 4 else ("f32" if args.precision == 6 else "f16"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic batch=32 gesture-only (GestSync conv + JEGAL gesture encoder), "
                                    "uint8 150x270x480x3 clips resident in HBM, seeded synthetic weights",
