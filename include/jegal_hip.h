@@ -88,11 +88,11 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "gemm_glds", "gemm_big_tile", "gemm_small_tile", "gemm_tall_tile", "gemm_persistent", "gemm_counted",
  *   "gemm_stagger":   tile / pipeline choices of the LDS-DMA GEMM (tests/test_gpu_options_scale_multirank.py flips every one of them)
  *   "gemm_tile"       0: plain GEMMs pick their tile by a measured cost estimate; 1 / 2 / 3: force 128x128 / 256x128 / 256x256 (bit-identical)
- *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) 3:5 and run the two parts concurrently on two internal
+ *   "dual_stream"     1: jg_extract_gesture and jg_gestsync_clip split a batch of >= 8 clips (and >= 256 frames in the smaller part) into two halves (option "dual_split": eighths of the batch on the first lane, default 4 since round 6; rounds 3-5: 3) and run the two parts concurrently on two internal
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
  *   "num_cu"          workgroups a persistent kernel launches (default: the device's CU count; experiment)
- *   "gesture_lanes"   0 (default): two lanes split 3:5; 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
+ *   "gesture_lanes"   0 (default): two lanes ("dual_split"); 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
  *   "xlmr_lanes"      1 (default) .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams.  More than one part is an
  *                     EXPERIMENT since round 6: rare run-to-run differences under a poisoned workspace, root cause open (api.hip, jg_handle::xl_lanes)
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a

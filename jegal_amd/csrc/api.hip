@@ -211,11 +211,13 @@ struct jg_handle {
     struct StageSlot { int32_t* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
     StageSlot stage_ring[16];
     unsigned stage_next = 0;
-    // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split 3:5 and the parts run concurrently on two
+    // jg_extract_gesture on two lanes (option "dual_stream"): the batch is split in two (dual_split) and the parts run concurrently on two
     // internal streams with their own workspaces, so that one part's next kernel fills the partly empty last round of the
     // other's (persistent kernels run in rounds of one tile per CU: 788 LayerNorm tiles on 256 CUs are 3.08 rounds)
     bool dual_stream = true;
-    int dual_split = 3;            // the first lane gets dual_split/8 of the batch
+    int dual_split = 4;            // the first lane gets dual_split/8 of the batch.  Round 6: equal halves (rounds 3-5: 3/8; with the run-time correction's
+                                   // small launches and the split-operand GEMMs in the mix the sweep reads 12.77 ms at 12:20, 12.57 at 14:18, 12.53-12.61 at 16:16,
+                                   // 12.57-12.66 at 17:15 / 18:14, 12.66-12.73 at 20:12 -- tools/dual_split_sweep.py)
     int dual_split32 = 0;          // option "dual_split32" (experiments): the first lane gets this many 32nds of the batch instead (0: use dual_split)
     int gesture_lanes = 0;         // option "gesture_lanes" (experiments): 3 / 4 = the gesture path runs as that many EQUAL parts (0: two lanes, dual_split)
     std::map<hipStream_t, Arena> ws_parked;      // arenas of the other streams this handle has been bound to (jg_set_stream)
