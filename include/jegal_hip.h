@@ -101,6 +101,8 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *   "jegal_fp32_ends" 1 (default): the two ends of the JEGAL gesture branch (proj_ip_rgb; final norm + proj_op_rgb + proj_op_align_gesture) and
  *                     of the content path (proj_op_text, fusion / align MLPs) keep fp32 activations and run on the split-operand GEMM
  *                     (three fp16 MFMAs per tile: fp32-grade products); 0: the round-5 arithmetic (fp16 activations, hi+lo weights).  DESIGN.md section 3
+ *   "jegal_ffn_x3"    0 (default) / 1: the six feed-forward sub-layers of the JEGAL gesture branch on the split-operand GEMM as well (gesture error
+ *                     3.5e-4 -> 2.5e-4 on the Gaussian draw for +3 % step time)
  *   "conv_round_diffuse" 1 (default; before jg_finalize_weights): conv weights are rounded to fp16 with error diffusion across the taps of each
  *                     (output channel, input slot) pair instead of round-to-nearest per weight (the pixel-independent part of the rounding error vanishes)
  *   "rc_layers"       measurement only: mask of the GestSync Linear types that get JG_PREC_FP16_RC's run-time correction (1 qkv, 2 out_proj,

@@ -232,6 +232,7 @@ struct jg_handle {
     // small GEMMs that carry two thirds of the branch's fp16 error -- run on the fp32 kernel in the fp16 contract modes
     int rc_layers = 15;            // experiment (option "rc_layers"): which Linear types of the GestSync transformer get the run-time correction
                                    // (mask of Lin::rc_type); the others run single fp16 WITHOUT a correction -- measurement only
+    bool jegal_ffn_x3 = false;     // option "jegal_ffn_x3": the JEGAL gesture branch's feed-forward sub-layers on the split-operand kernel too (measured, not default)
     bool jegal_fp32_ends = true;
     bool conv_round_diffuse = true;      // conv weights rounded with per-channel error diffusion across the taps (pack_matrix)
     bool audit_weights = false;
@@ -1124,7 +1125,7 @@ int annotated_encoder32(jg_handle* h, const EncLayer* layers, int nl, const LNp&
 
 // ONE sub-layer of a pre-norm encoder layer on the fp32 kernels, in place on the fp32 residual stream (which = 1: x += out(attn(qkv(LN1 x))),
 // 2: x += ff2(relu(ff1(LN2 x)))); scratch: M * (D + 3 D + D + Dff) floats.  (Diagnosis: annotated_encoder's `parts`.)
-int encoder_sublayers32(jg_handle* h, const EncLayer& L, int which, float* x32, float* scratch, const float* mask, int B, int S, int D, int Dff) {
+int encoder_sublayers32(jg_handle* h, const EncLayer& L, int which, float* x32, float* scratch, const float* mask, int B, int S, int D, int Dff, bool x3 = false) {
     const int M = B * S, H = 8, dk = D / H;
     float* n32 = scratch;
     float* qkv = n32 + (size_t)M * D;
@@ -1139,6 +1140,10 @@ int encoder_sublayers32(jg_handle* h, const EncLayer& L, int which, float* x32, 
     }
     Epi32 f; f.act = 1;
     RET(timed(h, JG_ST_NORM, [&] { return launch_layernorm(x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, n32, nullptr, h->stream); }));
+    if (x3) {          // option jegal_ffn_x3: fp32 activations, split in the loader, three fp16 MFMAs per tile (gemm_x3)
+        RET(gemm_x3(h, JG_ST_GEMM, n32, D, M, L.ff1, hid, f));
+        return gemm_x3(h, JG_ST_GEMM, hid, Dff, M, L.ff2, x32, r);
+    }
     RET(gemm32(h, JG_ST_GEMM, n32, D, M, L.ff1, hid, f));
     return gemm32(h, JG_ST_GEMM, hid, Dff, M, L.ff2, x32, r);
 }
@@ -1441,7 +1446,7 @@ int annotated_encoder(jg_handle* h, const EncLayer* layers, int nl, const LNp& f
             RET(gemm(h, JG_ST_GEMM, att, D, M, L.out, r));
         }
         if (parts & 4) {
-            RET(encoder_sublayers32(h, L, 2, x32, scr32, mask, B, S, D, Dff));
+            RET(encoder_sublayers32(h, L, 2, x32, scr32, mask, B, S, D, Dff, (parts & 16) != 0));
         } else {
             RET(timed(h, JG_ST_NORM, [&] { return LAUNCH(h, launch_layernorm, x32, L.n2.w, L.n2.b, M, D, LN_ANNOTATED, 0, nullptr, n16, h->stream); }));
             Epi f; f.relu = 1; f.out16 = hid;
@@ -1460,7 +1465,9 @@ int jegal_gestures_impl(jg_handle* h, const float* feats, const float* mask, int
     const int M = B * T;
     // the branch's two ends on the fp32 kernel (option jegal_fp32_ends; not in the plain-fp16 / bf16 reported modes, not while calibrating)
     const bool ends32 = h->jegal_fp32_ends && !h->calib && h->precision != JG_PREC_FP16 && h->precision != JG_PREC_BF16 && h->ip0.b32d && h->al_g2.b32d;
-    const int parts = h->audit_jegal_parts | (ends32 ? 9 : 0);
+    // option jegal_ffn_x3 (default off; DESIGN.md section 3 prices it): the six feed-forward sub-layers with fp32 activations on the split-operand kernel
+    const bool ffn_x3 = ends32 && h->jegal_ffn_x3 && !(h->audit_jegal_parts & 4) && (h->rgb_layers[0].ff1.wl || h->rgb_layers[0].ff1.wl_calib) && (h->rgb_layers[0].ff2.wl || h->rgb_layers[0].ff2.wl_calib);
+    const int parts = h->audit_jegal_parts | (ends32 ? 9 : 0) | (ffn_x3 ? 4 | 16 : 0);
     const bool ends_x3 = ends32 && !(h->audit_jegal_parts & 9);          // production: split operands on the fp16 matrix cores; diagnosis: fp32 MFMA
     f16 *f16in, *t16, *n16, *g16, *a16;
     float *t32, *x32, *n32 = nullptr;
@@ -2085,6 +2092,7 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "conv2_row_skip")) { h->conv2_row_skip = value != 0; return JG_OK; }
     if (!std::strcmp(name, "ws_poison")) { h->ws_poison = value != 0; return JG_OK; }
     if (!std::strcmp(name, "rc_layers")) { h->rc_layers = value & 15; return JG_OK; }
+    if (!std::strcmp(name, "jegal_ffn_x3")) { h->jegal_ffn_x3 = value != 0; return JG_OK; }
     if (!std::strcmp(name, "jegal_fp32_ends")) { h->jegal_fp32_ends = value != 0; return JG_OK; }
     if (!std::strcmp(name, "conv_round_diffuse")) {
         if (h->gs_ready || h->jg_ready) JG_FAIL(h, JG_ERR_STATE, "set conv_round_diffuse before jg_finalize_weights");

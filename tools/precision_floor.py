@@ -88,6 +88,7 @@ def main():
         run("rc ends=1 diffuse=0", L.PREC_FP16_RC, opts=[("conv_round_diffuse", 0)])
         run("rc ends=0 diffuse=1", L.PREC_FP16_RC, opts=[("jegal_fp32_ends", 0)])
         run("rc default", L.PREC_FP16_RC)
+        run("rc default + jegal_ffn_x3", L.PREC_FP16_RC, opts=[("jegal_ffn_x3", 1)])
         if args.rc_ablate:
             # which Linear types of the GestSync transformer need the run-time correction?  (option rc_layers: 1 qkv, 2 out_proj, 4 linear1 +
             # ff_vid.0, 8 linear2; the others run single fp16 without a correction -- measurement only)
