@@ -224,3 +224,35 @@ def test_audit_full_length_clip_vs_oracle(fp32, oracle_sd):
         g = O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0])
     print(f"\naudit T = 150: embedding rel-L2 {rel(emb[0], g):.2e} max-abs {maxabs(emb[0], g):.2e}", end="")
     assert rel(emb[0], g) < AUD_TOL and maxabs(emb[0], g) < AUD_TOL
+
+
+def test_split_operand_options_reduce_the_error(oracle_sd):
+    """Options jegal_fp32_ends (default on) and jegal_ffn_x3 (default off: +3 % step time) move GEMMs of the JEGAL branch to fp32 activations on
+    the split-operand kernel; conv_round_diffuse (default on) rounds conv weights with error diffusion across the taps.  Each must stay
+    inside the contract and the more exact arrangement must not be worse (T = 64, two clips; DESIGN.md section 3 has the T = 150 table)."""
+    from jegal_amd._lib import Engine, PREC_FP16_RC
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    gsd, jsd = oracle_sd
+    B, T = 2, 64
+    frames = synth.synth_frames(4242, B, T)
+    dev = torch.from_numpy(frames).cuda()
+    with torch.no_grad():
+        refs = []
+        for b in range(B):
+            f = O.gestsync_clip_feats(gsd, torch.from_numpy(frames[b].astype(np.float32) / np.float32(255.0)))
+            refs.append(O.l2_normalize(O.jegal_forward_inference(jsd, visual_feats=f[None], visual_mask=torch.ones(1, T))[0]).numpy())
+    errs = {}
+    for tag, opts in (("round5", {"jegal_fp32_ends": 0, "conv_round_diffuse": 0}), ("default", {}), ("ffn_x3", {"jegal_ffn_x3": 1})):
+        e = Engine(0, precision=PREC_FP16_RC)
+        try:
+            for k, v in opts.items():
+                e.set_option(k, v)
+            GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+            JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+            emb = e.extract_gesture(dev).cpu().numpy()
+        finally:
+            e.close()
+        errs[tag] = max(rel(emb[b], refs[b]) for b in range(B))
+    print("\ngesture rel-L2 (T = 64): " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()), end="")
+    assert errs["round5"] < 1e-3 and errs["default"] < 0.8 * errs["round5"] and errs["ffn_x3"] < 0.9 * errs["default"], errs
