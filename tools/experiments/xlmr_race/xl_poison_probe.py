@@ -1,7 +1,8 @@
-"""Debug probe: run-to-run differences of XLM-RoBERTa outputs (lanes, folding, poisoned workspace).
+"""Debug probe: run-to-run differences of XLM-RoBERTa outputs (lanes, folding, poisoned workspace).  Runs on the library as committed; the
+variants that need debug_scaffolding.patch are probe2-4.
 python tools/xl_poison_probe.py lanes fold [calibrate B L]"""
 import sys, os, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from jegal_amd import synth
 from jegal_amd._lib import Engine
@@ -25,7 +26,6 @@ base = xl(ids_d, attention_mask=mask_d).last_hidden_state.clone()
 n = 0
 seqs = set()
 eng.set_option("ws_poison", 1)
-eng.set_option("ws_poison_sel", int(os.environ.get("SEL", "0")))
 for it in range(150):
     eng.set_option("gemm_tile", it & 3)
     out = xl(ids_d, attention_mask=mask_d).last_hidden_state
@@ -34,15 +34,4 @@ for it in range(150):
     if len(bad):
         n += 1
         seqs |= set(int(b) for b, _ in bad)
-print(f"opts {os.environ.get('OPTS')} sel {os.environ.get('SEL')} lanes {lanes} fold {fold} calibrated {cal} B {B} L {L}: runs with differences: {n} of 150; sequences {sorted(seqs)}")
-import ctypes
-eng.lib.jg_debug_counter.restype = ctypes.c_int64
-eng.lib.jg_debug_counter.argtypes = [ctypes.c_void_p, ctypes.c_int]
-print("shadow launches, differing 16-byte words over all runs [attention, qkv, stats@qkv, ff1, stats@ff1]:", [eng.lib.jg_debug_counter(eng.h, i) for i in range(5)])
-buf = (ctypes.c_int64 * 96)()
-eng.lib.jg_debug_arenas.restype = ctypes.c_int
-nchunks = eng.lib.jg_debug_arenas(eng.h, buf, 32)
-for i in range(nchunks):
-    print("arena", buf[3 * i], hex(buf[3 * i + 1]), buf[3 * i + 2] >> 20, "MiB")
-for name, t in (("base", base), ("ids", ids_d), ("mask", mask_d)):
-    print(name, hex(t.data_ptr()), t.numel() * t.element_size())
+print(f"opts {os.environ.get('OPTS')} lanes {lanes} fold {fold} calibrated {cal} B {B} L {L}: runs with differences: {n} of 150; sequences {sorted(seqs)}")

@@ -1,6 +1,6 @@
 """Debug probe 2: what do the differing XLM-R outputs look like?  NaNs?  Equal to the no-mask result (mask buffer clobbered)?"""
 import sys, os, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from jegal_amd import synth
 from jegal_amd._lib import Engine

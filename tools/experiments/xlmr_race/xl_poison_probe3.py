@@ -1,6 +1,6 @@
 """Debug probe 3: group the outputs of N poisoned runs by equality (is the un-poisoned first run the odd one, or do the runs vary?)."""
 import sys, os, hashlib, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import jegal_oracle as O
 from jegal_amd import synth

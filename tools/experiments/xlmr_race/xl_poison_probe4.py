@@ -1,6 +1,6 @@
 """Debug probe 4 (JG_XL_ATTN_EXP=7): per-buffer checksums of every XLM-R pass; report the FIRST buffer that differs from the majority."""
 import sys, os, ctypes, collections, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from jegal_amd import synth
 from jegal_amd._lib import Engine
