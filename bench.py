@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for --oversubscribe)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing aid: allow more ranks than GPUs (ranks share devices round-robin; forces backend gloo; flagged in the output)")
+    ap.add_argument("--extra-streams", type=int, default=0, help="robustness experiment: the application owns this many other (used) streams before the engine exists")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=int (tuning experiments)")
     ap.add_argument("--only", default=None, choices=["config3"], help="run just one secondary measurement (for rocprofv3 summaries) and print its object")
     args = ap.parse_args()
@@ -312,6 +313,13 @@ def main():
     from jegal_amd._lib import Engine
     from jegal_amd.gestsync import GestSync
     from jegal_amd.jegal import JEGAL
+    extra_streams = []
+    for _ in range(args.extra_streams):          # each one used once, so the runtime has bound it to a hardware queue
+        st = torch.cuda.Stream(device=local_dev)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=f"cuda:{local_dev}").add_(1)
+        extra_streams.append(st)
+    torch.cuda.synchronize(local_dev)
     eng = Engine(local_dev, precision=args.precision)
     eng.set_chunk(args.chunk)
     for o in args.opt:

@@ -92,6 +92,11 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *                     streams (own workspaces; the caller's stream is joined at entry and exit): one part's next kernel fills
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
  *   "num_cu"          workgroups a persistent kernel launches (default: the device's CU count; experiment)
+ *   "lane_priority"   3 (default): the two lane streams are created with the device's highest stream priority; 0: normal priority (rounds 3-5);
+ *                     1 / 2: only the second / first lane.  Set it before the first two-lane call.  HIP deals streams onto four hardware
+ *                     queues PER PRIORITY LEVEL in creation order: normal-priority lanes can end up on one queue when the application owns
+ *                     other streams, and then the "concurrent" halves run in turn (measured: 2 076 instead of 2 510 clips/s with five other
+ *                     streams).  High-priority lanes only compete with the application's own high-priority streams.
  *   "gesture_lanes"   0 (default): two lanes ("dual_split"); 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
  *   "xlmr_lanes"      1 (default) .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams.  More than one part is an
  *                     EXPERIMENT since round 6: rare run-to-run differences under a poisoned workspace, root cause open (api.hip, jg_handle::xl_lanes)

@@ -249,6 +249,12 @@ struct jg_handle {
     // with xlmr_fold = 0 or attn_mfma = 0 (tools/experiments/xlmr_race/xl_poison_probe.py; the gesture path's two lanes: 0 of 150, tools/experiments/xlmr_race/gesture_race_probe.py).
     // Root cause not found; until it is, more than one part is an experiment (-8 % XLM-R throughput at B = 256, L = 64).
     int xl_lanes = 1;
+    // option "lane_priority" (before the first two-lane call): 0 = lane streams of normal priority; 1 / 2 = lane 1 / lane 0 of high priority; 3 = both
+    // (default since round 6).  The runtime deals streams onto hardware queues per PRIORITY LEVEL (four queues each, in creation order): with
+    // normal priority the two lanes can land on ONE queue and then run in turn -- measured with five other streams in the application:
+    // 2 076 instead of 2 510 clips/s (tools/experiments/lane_queue_sweep.sh) -- high-priority lanes get queues of their own whatever the
+    // application's normal-priority streams are doing (2 503-2 526 clips/s with 0 / 1 / 2 / 3 / 5 / 8 other streams)
+    int lane_priority = 3;
 };
 
 namespace {
@@ -1952,7 +1958,16 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int equal_lanes = 0) 
     for (int l = 0; l < nl; ++l) smallest = std::min(smallest, start[l + 1] - start[l]);
     if (!h->dual_stream || h->calib || nl < 2 || B < 8 || (long)smallest * T < 256 || audit_mask(h)) return run_part(0, B);
     for (int l = 0; l < nl; ++l)
-        if (!h->lane_stream[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+        if (!h->lane_stream[l]) {
+            const bool high = l < 2 && (h->lane_priority >> (l == 1 ? 0 : 1) & 1);
+            if (high) {
+                int least = 0, greatest = 0;
+                HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPCHK(h, hipStreamCreateWithPriority(&h->lane_stream[l], hipStreamNonBlocking, greatest));
+            } else {
+                HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+            }
+        }
     for (int e = 0; e < nl + 1; ++e)
         if (!h->lane_ev[e]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_ev[e], hipEventDisableTiming));
     hipStream_t user = h->stream;
@@ -2136,6 +2151,12 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     if (!std::strcmp(name, "dual_split32")) {
         if (value < 0 || value > 31) JG_FAIL(h, JG_ERR_ARG, "dual_split32 must be 0..31 (32nds of the batch on the first lane; 0 = use dual_split)");
         h->dual_split32 = value;
+        return JG_OK;
+    }
+    if (!std::strcmp(name, "lane_priority")) {
+        if (value < 0 || value > 3) JG_FAIL(h, JG_ERR_ARG, "lane_priority must be 0..3");
+        if (h->lane_stream[0] || h->lane_stream[1]) JG_FAIL(h, JG_ERR_STATE, "lane_priority must be set before the first two-lane call");
+        h->lane_priority = value;
         return JG_OK;
     }
     if (!std::strcmp(name, "dual_split")) {

@@ -308,6 +308,41 @@ def test_dual_stream_lanes_are_bit_identical_and_stream_ordered(engine, models):
     assert total == float(ref.double().sum().item())
 
 
+def test_lane_priority_option(models):
+    """The lane streams are created with the device's highest priority by default (their own hardware queues, whatever streams the
+    application owns); the option moves one or both back to normal priority.  Same bits in every setting, with a crowd of used
+    application streams around; the option is refused once the lane streams exist."""
+    from jegal_amd._lib import Engine, JegalError
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    gs, jg = models
+    crowd = []
+    for _ in range(6):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            torch.zeros(1, device="cuda").add_(1)
+        crowd.append(st)
+    torch.cuda.synchronize()
+    frames = torch.from_numpy(synth.synth_frames(4242, 16, 40)).cuda()
+    outs = []
+    for prio in (3, 0, 1, 2):
+        e = Engine(0)
+        try:
+            e.set_option("lane_priority", prio)
+            GestSync(engine=e).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+            JEGAL(engine=e).load_state_dict(synth.jegal_state_dict())
+            e.set_option("ws_poison", 1)
+            outs.append(e.extract_gesture(frames).clone())
+            with pytest.raises(JegalError, match="before the first two-lane call"):
+                e.set_option("lane_priority", 0)
+            with pytest.raises(JegalError, match="0..3"):
+                e.set_option("lane_priority", 4)
+        finally:
+            e.close()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_conv1_call_sequence_stress(engine, models):
     """Back-to-back conv1 launches of changing geometry (clip lengths 6..60, both paddings, zero-skip on and off) without any
     host synchronisation in between, each checked against the first result for its geometry.  Guards the hand-counted waits of the
