@@ -98,8 +98,8 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *                     other streams, and then the "concurrent" halves run in turn (measured: 2 076 instead of 2 510 clips/s with five other
  *                     streams).  High-priority lanes only compete with the application's own high-priority streams.
  *   "gesture_lanes"   0 (default): two lanes ("dual_split"); 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
- *   "xlmr_lanes"      1 (default) .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams.  More than one part is an
- *                     EXPERIMENT since round 6: rare run-to-run differences under a poisoned workspace, root cause open (api.hip, jg_handle::xl_lanes)
+ *   "xlmr_lanes"      2 (default), 1 .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams (the first two are the
+ *                     lane streams of "dual_stream" / "lane_priority")
  *   "ws_poison"       1 (test aid, default 0): the workspace is filled with 0xff bytes (fp16/fp32 NaN) before every clip chunk, so a
  *                     kernel that reads a row nobody wrote (the row / band skips leave rows unwritten on purpose) shows up as NaN
  *   "gemm_timeline"   1: print a per-tile phase timeline of every GEMM launch to stderr (debug)

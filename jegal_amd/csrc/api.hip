@@ -243,12 +243,12 @@ struct jg_handle {
     int audit_jegal_parts = 0;
     void* comm = nullptr;          // ncclComm_t of this rank (jg_comm_init) or nullptr
     int comm_rank = 0, comm_world = 1;
-    // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams.  Default 1 since round 6: with two
-    // parts in flight the implicit-LayerNorm pass returned, in 10-40 % of the runs under a POISONED workspace (option ws_poison: stale
-    // bytes are NaN instead of the previous, identical run's values), ~1e-2 errors on some sequences of one part -- never with one part, never
-    // with xlmr_fold = 0 or attn_mfma = 0 (tools/experiments/xlmr_race/xl_poison_probe.py; the gesture path's two lanes: 0 of 150, tools/experiments/xlmr_race/gesture_race_probe.py).
-    // Root cause not found; until it is, more than one part is an experiment (-8 % XLM-R throughput at B = 256, L = 64).
-    int xl_lanes = 1;
+    // option "xlmr_lanes": jg_xlmr_encode runs a batch as this many equal parts (1..4) on as many streams (default 2).  Round 6 ran it with 1 for
+    // a while: with two parts in flight the implicit-LayerNorm pass returned ~1e-2 errors on some sequences of one part in 10-40 % of the runs.
+    // Root cause (tools/experiments/xlmr_race/, tools/experiments/pk_opsel_mfma/repro.hip): on this GPU a v_pk_fma_f32 whose low half selects
+    // the HIGH register of its second operand (op_sel:[0,1,0], the consumer epilogue's `acc * rstd`) reads that operand as 0 in lanes 48-63
+    // while waves of another kernel issue MFMAs on the same SIMD.  The library is built without packed-fp32 instructions since (Makefile, NOPK).
+    int xl_lanes = 2;
     // option "lane_priority" (before the first two-lane call): 0 = lane streams of normal priority; 1 / 2 = lane 1 / lane 0 of high priority; 3 = both
     // (default since round 6).  The runtime deals streams onto hardware queues per PRIORITY LEVEL (four queues each, in creation order): with
     // normal priority the two lanes can land on ONE queue and then run in turn -- measured with five other streams in the application:

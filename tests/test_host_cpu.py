@@ -47,6 +47,27 @@ def test_hot_kernels_do_not_spill():
     assert not spilled, spilled
 
 
+def test_no_packed_fp32_instructions_in_the_library():
+    """Round 6: on MI355X a v_pk_{fma,mul,add}_f32 whose low half selects the HIGH register of its second operand (op_sel:[0,1,..], what hipcc
+    emits for `f32x4 * pair.y`) can read that operand as 0 in lanes 48-63 while waves of ANOTHER kernel issue MFMAs on the same SIMD
+    (tools/experiments/pk_opsel_mfma/repro.hip) -- that is how two concurrent XLM-RoBERTa passes corrupted each other.  The library is built
+    with the packed-fp32 feature off (csrc/Makefile, NOPK): no kernel may contain such an instruction, with or without selects."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import packed_opsel_scan as P
+    with_selects = {k: v for k, v in P.scan().items() if v}
+    assert not with_selects, {k: len(v) for k, v in with_selects.items()}
+    old = P.PAT
+    try:
+        P.PAT = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
+        res = P.scan()
+    finally:
+        P.PAT = old
+    assert len(res) >= 150                       # every kernel of every translation unit was looked at
+    packed = {k: len(v) for k, v in res.items() if v}
+    assert not packed, packed
+
+
 def test_engine_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -20,7 +20,29 @@ eng.set_option("xlmr_lanes", 2)
 for kv in os.environ.get("OPTS", "").split(","):
     if kv:
         eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-xl = XLMRoberta(engine=eng).load_state_dict(synth.xlmr_state_dict(layers=LAYERS))
+SD = synth.xlmr_state_dict(layers=LAYERS)
+xl = XLMRoberta(engine=eng).load_state_dict(SD)
+
+
+def host_terms(rows, c):
+    """For rows of the SECOND part (lane 1) and qkv column c, in float64: the accumulator term acc = W' . x, the row statistics (mean, rstd)
+    of the embedding sum x, the folded bias b' = b + W . beta and the column sum c1 = sum W' (W' = W * gamma): v = acc * rstd - c1 * mean * rstd + b'."""
+    g = lambda k: np.asarray(SD[k], np.float64)
+    i64 = ids.astype(np.int64)
+    nonpad = (i64 != 1).astype(np.int64)
+    pos = np.cumsum(nonpad, 1) * nonpad + 1
+    half = B // 2
+    bb, tt = half + rows // L, rows % L
+    x = g("embeddings.word_embeddings.weight")[i64[bb, tt]] + g("embeddings.token_type_embeddings.weight")[0] + g("embeddings.position_embeddings.weight")[pos[bb, tt]]
+    m = x.mean(1)
+    rs = 1.0 / np.sqrt(x.var(1) + 1e-5)
+    nm = ["query", "key", "value"][c // 768]
+    w = g(f"encoder.layer.0.attention.self.{nm}.weight")[c % 768]
+    bias = g(f"encoder.layer.0.attention.self.{nm}.bias")[c % 768]
+    gam, bet = g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias")
+    wf = w * gam
+    return x @ wf, m, rs, bias + w @ bet, wf.sum()
+
 ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
 fn = eng.lib.jg_debug_xl_buf
 fn.restype = ctypes.c_long
@@ -87,6 +109,15 @@ for it in range(RUNS):
             r = rr[cc == c]
             r0 = (r.min() // 16) * 16
             blk = slice(r0, r0 + 16)
+            acc_h, m_h, rs_h, b_h, c1_h = host_terms(np.arange(r0, r0 + 16), int(c))
+            want_h = acc_h * rs_h - c1_h * m_h * rs_h + b_h
+            h0 = b_h - c1_h * m_h * rs_h                         # the accumulator term missing
+            h1 = acc_h * m_h + h0                                # the accumulator scaled by the mean instead of rstd
+            h2 = acc_h * rs_h + b_h                              # the column-sum term missing
+            gotf = a16[blk, c].astype(np.float64)
+            err = lambda pred: float(np.abs(pred - gotf).max())
+            print(f"  HYPOTHESES col {c} rows {r0}..: max |host want - gpu want| {float(np.abs(want_h - b16[blk, c].astype(np.float64)).max()):.4f}; "
+                  f"max |prediction - got|: no accumulator term {err(h0):.4f}, accumulator x mean {err(h1):.4f}, no column-sum term {err(h2):.4f}, zero {err(0 * h0):.4f}")
             jj = (r0 % 32) // 16
             prev = b16[r0 - 16:r0, c] if r0 >= 16 else None
             print(f"  EVENT col {c} (mod 64: {c % 64}) rows {r0}.. j={jj} (128x128 tile) got==want[rows-16]: {prev is not None and np.array_equal(prev.view(np.uint16), a16[blk, c].view(np.uint16))}"

@@ -19,6 +19,10 @@ engs, xls, ins, streams, base = [], [], [], [], []
 for k in range(2):
     e = Engine(0)
     e.set_option("xlmr_lanes", 1)
+    if k == 0:
+        for kv in os.environ.get("OPTS_A", "").split(","):
+            if kv:
+                e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if k == 1:
         for kv in optsB.split(","):
             if kv:
@@ -27,7 +31,7 @@ for k in range(2):
     engs.append(e)
     ids, mask = synth.xlmr_inputs(3 + k, B, L)
     ins.append((torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()))
-    streams.append(torch.cuda.Stream())
+    streams.append(torch.cuda.Stream(priority=-1 if k == 1 else 0))      # B's stream of high priority: a hardware queue of the other pool, so A and B really overlap
 torch.cuda.synchronize()
 for k in range(2):
     base.append(xls[k](ins[k][0], attention_mask=ins[k][1]).last_hidden_state.clone())
@@ -44,6 +48,16 @@ def bench(which, n=200):
                 xls[k](ins[k][0], attention_mask=ins[k][1])
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 print(f"us per iteration: A alone {bench([0]):.0f}, B alone {bench([1]):.0f}, A and B on two streams {bench([0, 1]):.0f}")
+GEST = os.environ.get("GESTURE_B")              # handle B runs the GESTURE path instead (one lane): text on one stream, video on the other
+if GEST:
+    from jegal_amd.gestsync import GestSync
+    from jegal_amd.jegal import JEGAL
+    engs[1].set_option("dual_stream", 0)
+    GestSync(engine=engs[1]).load_state_dict(synth.gestsync_state_dict(include_unused=False))
+    JEGAL(engine=engs[1]).load_state_dict(synth.jegal_state_dict())
+    gframes = torch.from_numpy(synth.synth_frames(99, 8, 40)).cuda()
+    gbase = engs[1].extract_gesture(gframes).clone()
+    torch.cuda.synchronize()
 bad = [0, 0]
 for it in range(RUNS):
     outs = [None, None]
@@ -58,9 +72,12 @@ for it in range(RUNS):
                 torch.cuda._sleep(OFFSET)         # handle B trails handle A like lane 1 trails lane 0 (the host enqueues lane 0 first)
             if os.environ.get("POISON"):
                 engs[k].set_option("ws_poison", 1)
-            outs[k] = xls[k](ins[k][0], attention_mask=ins[k][1]).last_hidden_state
+            if k == 1 and GEST:
+                outs[k] = engs[1].extract_gesture(gframes)
+            else:
+                outs[k] = xls[k](ins[k][0], attention_mask=ins[k][1]).last_hidden_state
     torch.cuda.synchronize()
     for k in range(2):
-        if not torch.equal(outs[k], base[k]):
+        if not torch.equal(outs[k], gbase if (k == 1 and GEST) else base[k]):
             bad[k] += 1
-print(f"offset {OFFSET} cycles; B options [{optsB}] B {B} L {L} layers {LAYERS}: handle A (folded, MFMA attention) differs in {bad[0]} of {RUNS} runs, handle B in {bad[1]}")
+print(f"{'B = gesture path; ' if GEST else ''}offset {OFFSET} cycles; A options [{os.environ.get('OPTS_A', '')}] B options [{optsB}] B {B} L {L} layers {LAYERS}: handle A (folded, MFMA attention) differs in {bad[0]} of {RUNS} runs, handle B in {bad[1]}")
