@@ -59,7 +59,7 @@ def test_no_packed_fp32_instructions_in_the_library():
     assert not with_selects, {k: len(v) for k, v in with_selects.items()}
     old = P.PAT
     try:
-        P.PAT = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
+        P.PAT = re.compile(r"\bv_pk_((fma|mul|add)_f32|mov_b32)\b")           # v_pk_mov_b32 reads register pairs with selects too (same feature)
         res = P.scan()
     finally:
         P.PAT = old

@@ -57,6 +57,20 @@ __global__ __launch_bounds__(512) void victim(int loops, unsigned* bad, float* r
             case 5: asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); e0 = fma1(a.x, b.x, c.y); e1 = fma1(a.y, b.y, c.y); break;
             case 6: asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(c)); e0 = add1(a.x, c.y); e1 = add1(a.y, c.y); break;
             case 7: asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); e0 = mul1(a.x, b.y); e1 = mul1(a.y, b.x); break;
+            // packed fp16 (one 32-bit register per operand: the selects pick halves of a register, not registers of a pair) and v_fma_mix_f32
+            case 20: case 21: case 22: case 23: {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 ha = {(_Float16)(float)(lane & 31), (_Float16)(float)((lane & 31) + 1)}, hb = {(_Float16)0.5f, (_Float16)3.0f};
+                const h2 hc = {(_Float16)(float)(it & 63), (_Float16)(float)((it & 63) + 7)};
+                h2 hd;
+                float m0 = 0.f;
+                if (mode == 20) { asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(hd) : "v"(ha), "v"(hb), "v"(hc)); e0 = (float)ha.x * 3.0f + (float)hc.x; e1 = (float)ha.y * 3.0f + (float)hc.y; }
+                else if (mode == 21) { asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(hd) : "v"(ha), "v"(hb)); e0 = (float)ha.x * 3.0f; e1 = (float)ha.y * 3.0f; }
+                else if (mode == 22) { asm volatile("v_pk_add_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(hd) : "v"(ha), "v"(hc)); e0 = (float)ha.x + (float)hc.y; e1 = (float)ha.y + (float)hc.y; }
+                else { asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(m0) : "v"(ha), "v"(hb), "v"(c.x)); hd = h2{(_Float16)0.f, (_Float16)0.f}; e0 = (float)ha.x * 3.0f + c.x; e1 = 0.f; }
+                d = mode == 23 ? f32x2{m0, 0.f} : f32x2{(float)hd.x, (float)hd.y};
+                break;
+            }
             default: asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); e0 = fma1(a.y, b.y, c.y); e1 = fma1(a.x, b.x, c.x); break;
         }
         if (d.x != e0 || d.y != e1) {
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(256) void aggressor(int loops, float* sink, int kin
 
 static const char* FORMS[] = {"pk_fma op_sel:[0,1,0]", "pk_fma plain", "pk_fma op_sel_hi:[1,0,1]", "pk_mul op_sel:[0,1]", "pk_fma op_sel:[1,0,0]", "pk_fma op_sel:[0,0,1]",
                               "pk_add op_sel:[0,1]", "pk_mul op_sel:[0,1] op_sel_hi:[1,0]", "pk_fma op_sel:[1,1,1] op_sel_hi:[0,0,0]"};
+static const char* F16FORMS[] = {"pk_fma_f16 op_sel:[0,1,0]", "pk_mul_f16 op_sel:[0,1]", "pk_add_f16 op_sel:[0,1]", "fma_mix_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0]"};
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -126,7 +141,7 @@ int main(int argc, char** argv) {
     }
     unsigned nb; std::vector<float> r(64 * 8);
     CK(hipMemcpy(&nb, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), rec, 64 * 8 * 4, hipMemcpyDeviceToHost));
-    printf("aggressor kind %d (%s priority stream), victim form %s, victim LDS %d KB, %d launches x 256 workgroups x 512 threads x 200000 packed FMAs: %u wrong results\n", kind, high ? "high" : "normal", FORMS[mode % 100 < 9 ? mode % 100 : 8], lds / 1024, iters, nb);
+    printf("aggressor kind %d (%s priority stream), victim form %s, victim LDS %d KB, %d launches x 256 workgroups x 512 threads x 200000 packed FMAs: %u wrong results\n", kind, high ? "high" : "normal", (mode % 100 >= 20 ? F16FORMS[mode % 100 - 20] : FORMS[mode % 100 < 9 ? mode % 100 : 8]), lds / 1024, iters, nb);
     int lanes[4] = {0, 0, 0, 0}, lo_wrong = 0, hi_wrong = 0;
     for (unsigned k = 0; k < (nb < 64 ? nb : 64); ++k) { ++lanes[(int)r[8 * k] >> 4]; lo_wrong += r[8 * k + 1] != r[8 * k + 2]; hi_wrong += r[8 * k + 3] != r[8 * k + 4]; }
     if (nb) printf("  first %u records: lanes 0-15 %d, 16-31 %d, 32-47 %d, 48-63 %d; low half wrong %d, high half wrong %d\n", nb < 64 ? nb : 64, lanes[0], lanes[1], lanes[2], lanes[3], lo_wrong, hi_wrong);
