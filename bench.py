@@ -554,10 +554,13 @@ def main():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 got, emb_s = 0, None
+                stamps = []
                 for _, emb in st.run_filled(lambda pk, k: args.clips if k < nb else 0):
                     got += emb.shape[0]
                     emb_s = emb
+                    stamps.append((time.perf_counter() - t0) * 1e3)
                 extras["pcie_source_clips_per_s"] = got / (time.perf_counter() - t0)
+                print("source-resolution stream: batch completion times (ms) " + " ".join(f"{x:.1f}" for x in stamps), file=sys.stderr)
                 extras["pcie_source_bytes"] = st.packer[0].used
                 crops = torch.stack([eng.mask_resize(torch.from_numpy(src[b]), [my_src] * FRAMES) for b in range(args.clips)])
                 eng.extract_gesture(crops, out)

@@ -93,10 +93,12 @@ int jg_set_chunk(jg_handle* h, int clips_per_chunk);
  *                     the partly empty last round of the other's persistent kernels.  Bit-identical results.
  *   "num_cu"          workgroups a persistent kernel launches (default: the device's CU count; experiment)
  *   "lane_priority"   3 (default): the two lane streams are created with the device's highest stream priority; 0: normal priority (rounds 3-5);
- *                     1 / 2: only the second / first lane.  Set it before the first two-lane call.  HIP deals streams onto four hardware
+ *                     1 / 2: only the second / first lane (a change drains and re-creates the lane streams).  HIP deals streams onto four hardware
  *                     queues PER PRIORITY LEVEL in creation order: normal-priority lanes can end up on one queue when the application owns
  *                     other streams, and then the "concurrent" halves run in turn (measured: 2 076 instead of 2 510 clips/s with five other
- *                     streams).  High-priority lanes only compete with the application's own high-priority streams.
+ *                     streams).  High-priority lanes only compete with the application's own high-priority streams.  (A host-streaming pipeline around the engine -- GestureStreamer's
+ *                     H2D / D2H / compute streams -- in a process that owns further streams is the one measured case where 0 was faster:
+ *                     tools/experiments/stream_queue_sweep.sh)
  *   "gesture_lanes"   0 (default): two lanes ("dual_split"); 3 / 4: that many EQUAL lanes (experiment: slower, tools/experiments/README.md)
  *   "xlmr_lanes"      2 (default), 1 .. 4: jg_xlmr_encode runs a batch as that many equal parts on as many streams (the first two are the
  *                     lane streams of "dual_stream" / "lane_priority")

@@ -249,7 +249,7 @@ struct jg_handle {
     // the HIGH register of its second operand (op_sel:[0,1,0], the consumer epilogue's `acc * rstd`) reads that operand as 0 in lanes 48-63
     // while waves of another kernel issue MFMAs on the same SIMD.  The library is built without packed-fp32 instructions since (Makefile, NOPK).
     int xl_lanes = 2;
-    // option "lane_priority" (before the first two-lane call): 0 = lane streams of normal priority; 1 / 2 = lane 1 / lane 0 of high priority; 3 = both
+    // option "lane_priority": 0 = lane streams of normal priority; 1 / 2 = lane 1 / lane 0 of high priority; 3 = both
     // (default since round 6).  The runtime deals streams onto hardware queues per PRIORITY LEVEL (four queues each, in creation order): with
     // normal priority the two lanes can land on ONE queue and then run in turn -- measured with five other streams in the application:
     // 2 076 instead of 2 510 clips/s (tools/experiments/lane_queue_sweep.sh) -- high-priority lanes get queues of their own whatever the
@@ -2155,8 +2155,17 @@ int jg_set_option(jg_handle* h, const char* name, int value) {
     }
     if (!std::strcmp(name, "lane_priority")) {
         if (value < 0 || value > 3) JG_FAIL(h, JG_ERR_ARG, "lane_priority must be 0..3");
-        if (h->lane_stream[0] || h->lane_stream[1]) JG_FAIL(h, JG_ERR_STATE, "lane_priority must be set before the first two-lane call");
-        h->lane_priority = value;
+        if (value != h->lane_priority) {
+            // the lane streams are re-created (lazily, by the next two-lane call) with the new priority: drain and drop the old ones
+            DeviceGuard dg(h->device);
+            for (int l = 0; l < 2; ++l)
+                if (h->lane_stream[l]) {
+                    HIPCHK(h, hipStreamSynchronize(h->lane_stream[l]));
+                    HIPCHK(h, hipStreamDestroy(h->lane_stream[l]));
+                    h->lane_stream[l] = nullptr;
+                }
+            h->lane_priority = value;
+        }
         return JG_OK;
     }
     if (!std::strcmp(name, "dual_split")) {

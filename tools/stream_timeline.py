@@ -13,6 +13,13 @@ from jegal_amd.extract import GestureStreamer
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 MARKS = "--no-marks" not in sys.argv
+_crowd = []
+for _ in range(int(os.environ.get("EXTRA_STREAMS", "0"))):          # other (used) streams of the application, created before the engine
+    _s = torch.cuda.Stream()
+    with torch.cuda.stream(_s):
+        torch.zeros(1, device="cuda").add_(1)
+    _crowd.append(_s)
+torch.cuda.synchronize()
 eng = Engine(0); eng.set_chunk(32)
 for o in sys.argv[2:]:
     if "=" in o:
