@@ -1960,11 +1960,13 @@ int run_in_lanes(jg_handle* h, int B, int T, F&& run_part, int equal_lanes = 0) 
     for (int l = 0; l < nl; ++l)
         if (!h->lane_stream[l]) {
             const bool high = l < 2 && (h->lane_priority >> (l == 1 ? 0 : 1) & 1);
-            if (high) {
-                int least = 0, greatest = 0;
-                HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIPCHK(h, hipStreamCreateWithPriority(&h->lane_stream[l], hipStreamNonBlocking, greatest));
+            int least = 0, greatest = 0;
+            if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+                hipStreamCreateWithPriority(&h->lane_stream[l], hipStreamNonBlocking, greatest) == hipSuccess) {
+                // a lane of the high-priority queue pool
             } else {
+                (void)hipGetLastError();          // no priority levels on this device / runtime: a normal-priority lane
+                h->lane_stream[l] = nullptr;
                 HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
             }
         }
