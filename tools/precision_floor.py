@@ -109,7 +109,7 @@ def main():
         run("fp32", L.PREC_FP32)
         table[fam] = rows
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r6_precision_floor.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r6_precision_quick.json" if args.quick else "r6_precision_floor.json"), "w") as f:      # (--quick used to overwrite the full table)
         json.dump(table, f, indent=1, sort_keys=True)
 
 
